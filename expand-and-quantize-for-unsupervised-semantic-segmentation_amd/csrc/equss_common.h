@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels: error plumbing for the C ABI, vector types, bf16
+// conversion and wave-level reductions (wave = 64 lanes on CDNA4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/equss_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));   // 8 bf16 = one MFMA A/B fragment
+typedef short bf16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+#define EQUSS_WAVE 64
+
+namespace equss {
+
+// Per-thread message buffer behind equss_last_error().
+char* error_buffer();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        fail(0, "%s: %s", what, hipGetErrorString(e));
+        return -(int)e;
+    }
+    return EQUSS_OK;
+}
+
+// fp32 -> bf16, round to nearest even; hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950,
+// which keeps NaN a NaN.
+__device__ __forceinline__ u16 f2bf(float x) {
+    __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(u16, b);
+}
+__device__ __forceinline__ float bf2f(u16 b) {
+    return __builtin_bit_cast(float, (uint32_t)b << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+template <int WIDTH>
+__device__ __forceinline__ float group_sum(float v) {  // sum over WIDTH consecutive lanes
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <int WIDTH>
+__device__ __forceinline__ float group_max(float v) {
+#pragma unroll
+    for (int off = WIDTH / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+}  // namespace equss

@@ -1,0 +1,487 @@
+// Product-quantisation assign for gfx950: per sub-space nearest-codeword search in exact fp32.
+//
+// Follows Codebook.forward / ProductQuantizerWrapper.forward (model/dino_pqgo.py:579-705,:745-776)
+// and the same core of model/quantizer.py (:120-153, :419-476): normalise rows and codebook,
+// dist = (sum zn^2 + sum cn^2) - 2 <zn, cn>, first arg-min, gather, straight-through output and
+// the mse numerator.
+//
+// Mapping to the machine
+//  * One workgroup serves one sub-space p and walks a strided list of row tiles.  Its waves pin
+//    the (normalised) codebook of p in registers for the whole launch: wave `wk` holds NT tiles
+//    of 32 codewords as the A operand of v_mfma_f32_32x32x2_f32, which is an exact fp32 fma chain
+//    (k ascending), so no precision is traded for the matrix pipe.
+//  * Rows stream HBM -> registers (coalesced 16 B per lane) -> normalise (lanes that share a row
+//    reduce with wave shuffles) -> XOR-swizzled LDS tile.  Every wave reads the tile back as the B
+//    operand with conflict-free ds_read_b128.
+//  * The MFMA result puts a row on each lane and 16 codewords in its registers, so the arg-min is
+//    an in-lane scan, one cross-half shuffle, and (when several waves split K) a tiny LDS pass.
+//  * The epilogue re-reads the normalised row from LDS, gathers the chosen codeword (L2 resident)
+//    and writes zq / idx coalesced; per-workgroup loss partials are summed in a fixed order by a
+//    second tiny kernel, so the loss is bitwise reproducible run to run.
+#include "equss_common.h"
+
+namespace {
+
+using equss::group_sum;
+
+constexpr int kMaxGridX = 1024;
+
+template <int D>
+__device__ __forceinline__ int swz_chunk(int r, int c) {
+    constexpr int CPR = D / 4;  // 16-byte chunks per row
+    if constexpr (CPR >= 16) {
+        return c ^ (r & 15);
+    } else {
+        constexpr int RPB = 16 / CPR;  // rows per 256-byte bank row
+        return c ^ ((r / RPB) & (CPR - 1));
+    }
+}
+
+// Normalise one row held as one float4 per lane over D/4 consecutive lanes.
+// Returns sum(v_normalised^2) (the "sum z^2" term of the distance).
+template <int D>
+__device__ __forceinline__ float normalize_row(f32x4& v, int mode) {
+    constexpr int LPR = D / 4;
+    if (mode == EQUSS_NORM_L2) {  // F.normalize(dim=1, eps=1e-12): x / max(||x||, eps)
+        float s = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        s = group_sum<LPR>(s);
+        float den = fmaxf(sqrtf(s), 1e-12f);
+        v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+    } else if (mode == EQUSS_NORM_ZSCORE) {  // (x - mean) / (unbiased std + 1e-5)
+        float m = group_sum<LPR>(v.x + v.y + v.z + v.w) / (float)D;
+        v.x -= m; v.y -= m; v.z -= m; v.w -= m;
+        float q = group_sum<LPR>(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+        float den = sqrtf(q / (float)(D - 1)) + 1e-5f;
+        v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+    }
+    float a = v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    return group_sum<LPR>(a);
+}
+
+// cn = normalise(codebook rows), csq = sum(cn^2) per row.
+template <int D>
+__global__ void pq_prep_codebook(const float* __restrict__ cb, float* __restrict__ cn,
+                                 float* __restrict__ csq, int total_rows, int mode) {
+    constexpr int LPR = D / 4;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = gid / LPR, c = gid % LPR;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < total_rows) v = *reinterpret_cast<const f32x4*>(cb + (size_t)row * D + 4 * c);
+    const float a = normalize_row<D>(v, mode);
+    if (row < total_rows) {
+        *reinterpret_cast<f32x4*>(cn + (size_t)row * D + 4 * c) = v;
+        if (c == 0) csq[row] = a;
+    }
+}
+
+struct PqArgs {
+    const float* code; int64_t ld_code;
+    const float* cn; const float* csq; const float* gather;  // gather: raw or normalised codebooks
+    int64_t* idx; float* zq; int64_t ld_zq; float* loss_partial;
+    int rows, num_pq, K, ntiles, mode, WK, WR, RT;
+};
+
+constexpr int kPqThreads = 512;   // 8 waves: two per SIMD, one workgroup per CU at <= 256 VGPRs
+constexpr int kPqMaxItems = 8;    // float4 items a thread stages per row tile (upper bound)
+
+template <int D, int NT, int ITEMS>
+__global__ __launch_bounds__(kPqThreads, 2) void pq_assign_kernel(const PqArgs a) {
+    constexpr int LPR = D / 4;
+    constexpr int THREADS = kPqThreads;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int WK = a.WK, RT = a.RT, K = a.K;
+    const int R = 32 * a.WR * RT;
+    const int wk = wave % WK, wr = wave / WK;
+    const int p = blockIdx.y;
+    const int li = lane & 31, lh = lane >> 5;
+
+    float* zt = reinterpret_cast<float*>(smem);  // R x D, chunk-swizzled
+    float* rowA = zt + (size_t)R * D;            // R
+    float* csq_s = rowA + R;                     // K
+    float* cand_d = csq_s + K;                   // WK x R
+    int* cand_i = reinterpret_cast<int*>(cand_d + (size_t)WK * R);
+    int* fin_idx = cand_i + (size_t)WK * R;      // R
+
+    // Codebook slice of this wave -> registers, laid out as MFMA A operands: lane (i, h) keeps
+    // cn[cw0 + 32 nt + i][8 t + 4 h + u] in cbr[nt][4 t + u]; the B operand uses the same k order.
+    const int cw0 = wk * 32 * NT;
+    float cbr[NT][D / 2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.cn + ((size_t)p * K + cw0 + nt * 32 + li) * D);
+#pragma unroll
+        for (int t = 0; t < D / 8; ++t) {
+            const f32x4 c = src[2 * t + lh];
+            cbr[nt][4 * t + 0] = c.x; cbr[nt][4 * t + 1] = c.y;
+            cbr[nt][4 * t + 2] = c.z; cbr[nt][4 * t + 3] = c.w;
+        }
+    }
+    for (int k = tid; k < K; k += THREADS) csq_s[k] = a.csq[(size_t)p * K + k];
+
+    float loss = 0.f;
+
+    // Rows of the next tile travel HBM -> registers while the current tile is on the matrix pipe.
+    f32x4 pre[ITEMS];  // ITEMS = R * LPR / THREADS float4 per thread per tile
+    auto fetch = [&](int tile) {
+        const int row0 = tile * R;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = it * THREADS + tid;
+            const int grow = row0 + item / LPR;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (tile < a.ntiles && grow < a.rows)
+                v = *reinterpret_cast<const f32x4*>(a.code + (size_t)grow * a.ld_code + (size_t)p * D +
+                                                    4 * (item % LPR));
+            pre[it] = v;
+        }
+    };
+    fetch(blockIdx.x);
+
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const int row0 = tile * R;
+        // ---- stage: normalise the fetched rows -> LDS ----------------------------------------
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = it * THREADS + tid;
+            const int r = item / LPR, c = item % LPR;
+            f32x4 v = pre[it];
+            const float sa = normalize_row<D>(v, a.mode);
+            *reinterpret_cast<f32x4*>(zt + ((size_t)r * LPR + swz_chunk<D>(r, c)) * 4) = v;
+            if (c == 0) rowA[r] = sa;
+        }
+        __syncthreads();
+        fetch(tile + gridDim.x);
+        // ---- distances on the matrix pipe + in-lane arg-min ---------------------------------
+        for (int rt = 0; rt < RT; ++rt) {
+            const int row = (wr * RT + rt) * 32 + li;
+            const float* zrow = zt + (size_t)row * D;
+            const float arow = rowA[row];
+            float best = __builtin_inff();
+            int besti = 0;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                // one 16-byte chunk of the row feeds four MFMAs; the next chunk is read while they
+                // issue, and the scheduling fence keeps the compiler from hoisting every read of the
+                // row (64 registers at d = 128) to the top.
+                f32x4 z = *reinterpret_cast<const f32x4*>(zrow + swz_chunk<D>(row, lh) * 4);
+#pragma unroll
+                for (int t = 0; t < D / 8; ++t) {
+                    f32x4 zn = z;
+                    if (t + 1 < D / 8)
+                        zn = *reinterpret_cast<const f32x4*>(zrow + swz_chunk<D>(row, 2 * (t + 1) + lh) * 4);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cbr[nt][4 * t + 0], z.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cbr[nt][4 * t + 1], z.y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cbr[nt][4 * t + 2], z.z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(cbr[nt][4 * t + 3], z.w, acc, 0, 0, 0);
+                    z = zn;
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // acc[reg] = <cn[cw], zn[row]> with cw = cw0 + 32 nt + (reg&3) + 8 (reg>>2) + 4 h
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int cw = cw0 + nt * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * lh;
+                    const float t0 = arow + csq_s[cw];
+                    const float dist = t0 - 2.0f * acc[reg];
+                    if (dist < best) { best = dist; besti = cw; }
+                }
+            }
+            const float od = __shfl_xor(best, 32, 64);
+            const int oi = __shfl_xor(besti, 32, 64);
+            if (od < best || (od == best && oi < besti)) { best = od; besti = oi; }
+            if (lh == 0) { cand_d[wk * R + row] = best; cand_i[wk * R + row] = besti; }
+        }
+        __syncthreads();
+        // ---- first minimum across the waves that split K -------------------------------------
+        if (tid < R) {
+            float b = cand_d[tid];
+            int bi = cand_i[tid];
+            for (int w = 1; w < WK; ++w) {
+                const float d2 = cand_d[w * R + tid];
+                if (d2 < b) { b = d2; bi = cand_i[w * R + tid]; }
+            }
+            fin_idx[tid] = bi;
+            if (row0 + tid < a.rows) a.idx[(size_t)p * a.rows + row0 + tid] = (int64_t)bi;
+        }
+        __syncthreads();
+        // ---- gather + straight-through output + mse numerator --------------------------------
+        for (int it = 0; it < ITEMS; ++it) {
+            const int item = it * THREADS + tid;
+            const int r = item / LPR, c = item % LPR;
+            const int grow = row0 + r;
+            if (grow < a.rows) {
+                const int k = fin_idx[r];
+                const f32x4 zn = *reinterpret_cast<const f32x4*>(zt + ((size_t)r * LPR + swz_chunk<D>(r, c)) * 4);
+                const f32x4 e = *reinterpret_cast<const f32x4*>(a.gather + ((size_t)p * K + k) * D + 4 * c);
+                f32x4 df; df.x = e.x - zn.x; df.y = e.y - zn.y; df.z = e.z - zn.z; df.w = e.w - zn.w;
+                loss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+                if (a.zq) {
+                    f32x4 q; q.x = zn.x + df.x; q.y = zn.y + df.y; q.z = zn.z + df.z; q.w = zn.w + df.w;
+                    *reinterpret_cast<f32x4*>(a.zq + (size_t)grow * a.ld_zq + (size_t)p * D + 4 * c) = q;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // ---- per-workgroup loss partial (fixed order, no atomics) ----------------------------------
+    loss = group_sum<64>(loss);
+    if (lane == 0) cand_d[wave] = loss;  // cand_d is free after the last barrier
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < THREADS / 64; ++w) s += cand_d[w];
+        a.loss_partial[(size_t)p * kMaxGridX + blockIdx.x] = s;
+    }
+}
+
+__global__ void pq_loss_reduce(const float* __restrict__ partial, float* __restrict__ loss_sum, int gx) {
+    const int p = blockIdx.x;
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < gx; ++i) s += partial[(size_t)p * kMaxGridX + i];
+        loss_sum[p] = s;
+    }
+}
+
+// softmax(-dist * inv_tau) over K for every (row, sub-space).  One workgroup per row tile of 4
+// rows; not on the timed path (the eval loop never consumes it), so plain fp32 VALU code.
+template <int D>
+__global__ __launch_bounds__(256) void pq_prob_kernel(const float* __restrict__ code, int64_t ld_code,
+                                                      const float* __restrict__ cn,
+                                                      const float* __restrict__ csq, float* __restrict__ prob,
+                                                      int rows, int num_pq, int K, int mode, float inv_tau) {
+    constexpr int LPR = D / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* zn = reinterpret_cast<float*>(smem);  // D
+    float* dist = zn + D;                        // K
+    float* red = dist + K;                       // 4 maxima, 4 sums, row sum-of-squares
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x, p = blockIdx.y;
+    if (tid < 64) {  // one wave normalises the row (LPR <= 32 lanes carry data)
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (tid < LPR) v = *reinterpret_cast<const f32x4*>(code + (size_t)row * ld_code + (size_t)p * D + 4 * tid);
+        const float sa = normalize_row<D>(v, mode);
+        if (tid < LPR) *reinterpret_cast<f32x4*>(zn + 4 * tid) = v;
+        if (tid == 0) red[8] = sa;
+    }
+    __syncthreads();
+    const float arow = red[8];
+    float lmax = -__builtin_inff();
+    for (int k = tid; k < K; k += 256) {
+        const float* c = cn + ((size_t)p * K + k) * D;
+        float dot = 0.f;
+        for (int j = 0; j < D; ++j) dot = fmaf(zn[j], c[j], dot);
+        const float t0 = arow + csq[(size_t)p * K + k];
+        const float dd = -(t0 - 2.0f * dot) * inv_tau;
+        dist[k] = dd;
+        lmax = fmaxf(lmax, dd);
+    }
+    lmax = equss::group_max<64>(lmax);
+    if ((tid & 63) == 0) red[tid >> 6] = lmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float lsum = 0.f;
+    for (int k = tid; k < K; k += 256) {
+        const float e = expf(dist[k] - m);
+        dist[k] = e;
+        lsum += e;
+    }
+    lsum = group_sum<64>(lsum);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lsum;
+    __syncthreads();
+    const float s = (red[4] + red[5]) + (red[6] + red[7]);
+    for (int k = tid; k < K; k += 256)
+        prob[(size_t)row * num_pq * K + (size_t)p * K + k] = dist[k] / s;
+}
+
+struct PqPlan { int NT, WK, WR, RT, R; };
+
+// Split of the 8 waves of a workgroup: WK waves share K (each pins NT tiles of 32 codewords),
+// WR groups share the rows of a tile, every group walks RT row tiles of 32.
+bool make_plan(int K, int d, PqPlan* pl) {
+    if (d != 16 && d != 32 && d != 64 && d != 128) return false;
+    if (K <= 0 || K % 32 != 0) return false;
+    const int tiles = K / 32;
+    int nt = 128 / d;  // pinned codebook <= 64 registers per lane
+    if (nt > 8) nt = 8;
+    while (nt > 1 && (tiles % nt != 0)) nt >>= 1;
+    int wk = tiles / nt;
+    if (wk > 8 && (wk % 2 == 0) && nt * 2 * (d / 2) <= 128 && nt * 2 <= 8) { nt *= 2; wk /= 2; }  // <= 128 registers
+    if (wk > 8 || (wk & (wk - 1)) != 0) return false;
+    const int wr = 8 / wk;
+    int rt = wr == 1 ? 2 : 1;
+    int r = 32 * wr * rt;
+    while (r * (d / 4) < kPqThreads) { rt *= 2; r *= 2; }  // at least one float4 per thread per tile
+    if ((r * (d / 4)) / kPqThreads > kPqMaxItems) return false;
+    pl->NT = nt; pl->WK = wk; pl->WR = wr; pl->RT = rt; pl->R = r;
+    return true;
+}
+
+size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+struct PqWorkspace { float* cn; float* csq; float* loss_partial; size_t bytes; };
+
+PqWorkspace carve(void* ws, int num_pq, int K, int d) {
+    PqWorkspace w;
+    size_t off = 0;
+    char* base = reinterpret_cast<char*>(ws);
+    w.cn = reinterpret_cast<float*>(base + off); off += align256((size_t)num_pq * K * d * 4);
+    w.csq = reinterpret_cast<float*>(base + off); off += align256((size_t)num_pq * K * 4);
+    w.loss_partial = reinterpret_cast<float*>(base + off); off += align256((size_t)num_pq * kMaxGridX * 4);
+    w.bytes = off;
+    return w;
+}
+
+template <int D>
+int launch_prep(const float* cb, const PqWorkspace& w, int total_rows, int mode, hipStream_t s) {
+    const int threads = 256;
+    const long items = (long)total_rows * (D / 4);
+    const int blocks = (int)((items + threads - 1) / threads);
+    hipLaunchKernelGGL(pq_prep_codebook<D>, dim3(blocks), dim3(threads), 0, s, cb, w.cn, w.csq, total_rows, mode);
+    return equss::check_launch("pq_prep_codebook");
+}
+
+template <int D, int NT, int ITEMS>
+int launch_assign_items(const PqArgs& a, const PqPlan& pl, int gx, hipStream_t s) {
+    const size_t lds = ((size_t)pl.R * D + pl.R + a.K + 2 * (size_t)pl.WK * pl.R + pl.R) * 4;
+    auto kern = pq_assign_kernel<D, NT, ITEMS>;
+    if (lds > 65536 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+        return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(kern, dim3(gx, a.num_pq), dim3(kPqThreads), lds, s, a);
+    return equss::check_launch("pq_assign_kernel");
+}
+
+template <int D, int NT>
+int launch_assign(const PqArgs& a, const PqPlan& pl, int gx, hipStream_t s) {
+    switch ((pl.R * (D / 4)) / kPqThreads) {
+        case 1: return launch_assign_items<D, NT, 1>(a, pl, gx, s);
+        case 2: return launch_assign_items<D, NT, 2>(a, pl, gx, s);
+        case 4: return launch_assign_items<D, NT, 4>(a, pl, gx, s);
+        case 8: return launch_assign_items<D, NT, 8>(a, pl, gx, s);
+        default: break;
+    }
+    return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: no kernel for a %d-row tile at d=%d", pl.R, D);
+}
+
+template <int D>
+int dispatch_nt(const PqArgs& a, const PqPlan& pl, int gx, hipStream_t s) {
+    switch (pl.NT) {
+        case 1: return launch_assign<D, 1>(a, pl, gx, s);
+        case 2: return launch_assign<D, 2>(a, pl, gx, s);
+        case 4: if constexpr (D <= 64) return launch_assign<D, 4>(a, pl, gx, s); break;
+        case 8: if constexpr (D <= 32) return launch_assign<D, 8>(a, pl, gx, s); break;
+        default: break;
+    }
+    return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: no kernel for d=%d NT=%d", D, pl.NT);
+}
+
+int check_common(const float* code, int64_t ld_code, const float* codebooks, void* workspace,
+                 size_t workspace_bytes, int rows, int num_pq, int K, int d, int normalize, PqPlan* pl) {
+    if (!code || !codebooks || !workspace) return equss::fail(EQUSS_E_NULL, "pq: null pointer argument");
+    if (rows <= 0 || num_pq <= 0 || K <= 0 || d <= 0)
+        return equss::fail(EQUSS_E_SHAPE, "pq: rows=%d num_pq=%d K=%d d=%d must be positive", rows, num_pq, K, d);
+    if (normalize < EQUSS_NORM_NONE || normalize > EQUSS_NORM_ZSCORE)
+        return equss::fail(EQUSS_E_UNSUPPORTED, "pq: unsupported normalize mode %d", normalize);
+    if (!make_plan(K, d, pl))
+        return equss::fail(EQUSS_E_UNSUPPORTED,
+                           "pq: unsupported shape K=%d d=%d (d in {16,32,64,128}; K/32 a power-of-two multiple "
+                           "of the per-wave tile count, at most 16 waves)", K, d);
+    if (ld_code < (int64_t)num_pq * d || (ld_code % 4) != 0 || ((uintptr_t)code % 16) != 0 ||
+        ((uintptr_t)codebooks % 16) != 0 || ((uintptr_t)workspace % 256) != 0)
+        return equss::fail(EQUSS_E_ALIGN, "pq: code/codebooks must be 16-byte aligned, workspace 256-byte aligned, "
+                                          "ld_code a multiple of 4 and >= num_pq*d");
+    if (workspace_bytes < equss_pq_workspace_bytes(rows, num_pq, K, d))
+        return equss::fail(EQUSS_E_WORKSPACE, "pq: workspace of %zu bytes is smaller than the %zu required",
+                           workspace_bytes, equss_pq_workspace_bytes(rows, num_pq, K, d));
+    return EQUSS_OK;
+}
+
+}  // namespace
+
+extern "C" size_t equss_pq_workspace_bytes(int rows, int num_pq, int K, int d) {
+    (void)rows;
+    if (num_pq <= 0 || K <= 0 || d <= 0) return 0;
+    return carve(nullptr, num_pq, K, d).bytes;
+}
+
+extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
+                               float* zq, int64_t ld_zq, float* loss_sum, void* workspace,
+                               size_t workspace_bytes, int rows, int num_pq, int K, int d, int normalize,
+                               int gather_normalized, void* stream) {
+    PqPlan pl;
+    int rc = check_common(code, ld_code, codebooks, workspace, workspace_bytes, rows, num_pq, K, d, normalize, &pl);
+    if (rc) return rc;
+    if (!idx) return equss::fail(EQUSS_E_NULL, "pq_assign: idx is null");
+    if (zq && (ld_zq < (int64_t)num_pq * d || (ld_zq % 4) != 0 || ((uintptr_t)zq % 16) != 0))
+        return equss::fail(EQUSS_E_ALIGN, "pq_assign: zq must be 16-byte aligned with ld_zq a multiple of 4");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PqWorkspace w = carve(workspace, num_pq, K, d);
+    switch (d) {
+        case 16: rc = launch_prep<16>(codebooks, w, num_pq * K, normalize, s); break;
+        case 32: rc = launch_prep<32>(codebooks, w, num_pq * K, normalize, s); break;
+        case 64: rc = launch_prep<64>(codebooks, w, num_pq * K, normalize, s); break;
+        default: rc = launch_prep<128>(codebooks, w, num_pq * K, normalize, s); break;
+    }
+    if (rc) return rc;
+    PqArgs a;
+    a.code = code; a.ld_code = ld_code; a.cn = w.cn; a.csq = w.csq;
+    a.gather = gather_normalized ? w.cn : codebooks;
+    a.idx = idx; a.zq = zq; a.ld_zq = ld_zq; a.loss_partial = w.loss_partial;
+    a.rows = rows; a.num_pq = num_pq; a.K = K; a.mode = normalize;
+    a.WK = pl.WK; a.WR = pl.WR; a.RT = pl.RT;
+    a.ntiles = (rows + pl.R - 1) / pl.R;
+    int gx = (256 + num_pq - 1) / num_pq;  // one resident workgroup per CU
+    if (gx > a.ntiles) gx = a.ntiles;
+    if (gx > kMaxGridX) gx = kMaxGridX;
+    if (gx < 1) gx = 1;
+    switch (d) {
+        case 16: rc = dispatch_nt<16>(a, pl, gx, s); break;
+        case 32: rc = dispatch_nt<32>(a, pl, gx, s); break;
+        case 64: rc = dispatch_nt<64>(a, pl, gx, s); break;
+        default: rc = dispatch_nt<128>(a, pl, gx, s); break;
+    }
+    if (rc) return rc;
+    if (loss_sum) {
+        hipLaunchKernelGGL(pq_loss_reduce, dim3(num_pq), dim3(64), 0, s, w.loss_partial, loss_sum, gx);
+        rc = equss::check_launch("pq_loss_reduce");
+    }
+    return rc;
+}
+
+extern "C" int equss_pq_prob(const float* code, int64_t ld_code, const float* codebooks, float* prob,
+                             void* workspace, size_t workspace_bytes, int rows, int num_pq, int K, int d,
+                             int normalize, float inv_tau, void* stream) {
+    PqPlan pl;
+    int rc = check_common(code, ld_code, codebooks, workspace, workspace_bytes, rows, num_pq, K, d, normalize, &pl);
+    if (rc) return rc;
+    if (!prob) return equss::fail(EQUSS_E_NULL, "pq_prob: prob is null");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    PqWorkspace w = carve(workspace, num_pq, K, d);
+    const size_t lds = ((size_t)d + K + 16) * 4;
+    switch (d) {
+        case 16:
+            rc = launch_prep<16>(codebooks, w, num_pq * K, normalize, s);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<16>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            break;
+        case 32:
+            rc = launch_prep<32>(codebooks, w, num_pq * K, normalize, s);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<32>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            break;
+        case 64:
+            rc = launch_prep<64>(codebooks, w, num_pq * K, normalize, s);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<64>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            break;
+        default:
+            rc = launch_prep<128>(codebooks, w, num_pq * K, normalize, s);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<128>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            break;
+    }
+    if (rc) return rc;
+    return equss::check_launch("pq_prob_kernel");
+}

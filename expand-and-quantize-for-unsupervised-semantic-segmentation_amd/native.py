@@ -1,0 +1,297 @@
+"""ctypes binding of libequss_hip.so (the C ABI declared in include/equss_hip.h) plus thin
+tensor-level wrappers.  PyTorch only supplies device memory and the current stream here; every
+computation below runs in the hand-written gfx950 kernels.  There is no fallback: if the library
+is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import threading
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libequss_hip.so")
+
+NORM_MODES = {"none": 0, "l2": 1, "z_norm": 2}
+EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3, 4
+
+EXPORTED_SYMBOLS = [
+    "equss_abi_version", "equss_last_error",
+    "equss_pq_workspace_bytes", "equss_pq_assign", "equss_pq_prob",
+    "equss_layernorm_bf16", "equss_gemm_bf16", "equss_attention_bf16",
+    "equss_patch_workspace_bytes", "equss_patch_tokens",
+    "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
+]
+
+
+class EqussError(RuntimeError):
+    pass
+
+
+class VitBlockStruct(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "ln1_g", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b",
+        "ln2_g", "ln2_b", "fc1_w", "fc1_b", "fc2_w", "fc2_b")]
+
+
+class VitStruct(ctypes.Structure):
+    _fields_ = [("embed_dim", ctypes.c_int32), ("depth", ctypes.c_int32), ("heads", ctypes.c_int32),
+                ("patch", ctypes.c_int32),
+                ("patch_w", ctypes.c_void_p), ("patch_b", ctypes.c_void_p), ("cls", ctypes.c_void_p),
+                ("norm_g", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
+                ("blocks", ctypes.POINTER(VitBlockStruct))]
+
+
+_lib = None
+_lock = threading.Lock()
+
+
+def _declare(lib):
+    c_int, c_i64, c_vp, c_sz, c_f = ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_float
+    lib.equss_abi_version.restype = c_int
+    lib.equss_abi_version.argtypes = []
+    lib.equss_last_error.restype = ctypes.c_char_p
+    lib.equss_last_error.argtypes = []
+    lib.equss_pq_workspace_bytes.restype = c_sz
+    lib.equss_pq_workspace_bytes.argtypes = [c_int] * 4
+    lib.equss_pq_assign.restype = c_int
+    lib.equss_pq_assign.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz,
+                                    c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_pq_prob.restype = c_int
+    lib.equss_pq_prob.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]
+    lib.equss_layernorm_bf16.restype = c_int
+    lib.equss_layernorm_bf16.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_f, c_vp]
+    lib.equss_gemm_bf16.restype = c_int
+    lib.equss_gemm_bf16.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_attention_bf16.restype = c_int
+    lib.equss_attention_bf16.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_f, c_vp]
+    lib.equss_patch_workspace_bytes.restype = c_sz
+    lib.equss_patch_workspace_bytes.argtypes = [c_int] * 5
+    lib.equss_patch_tokens.restype = c_int
+    lib.equss_patch_tokens.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                       c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_vit_workspace_bytes.restype = c_sz
+    lib.equss_vit_workspace_bytes.argtypes = [ctypes.POINTER(VitStruct), c_int, c_int, c_int]
+    lib.equss_vit_forward.restype = c_int
+    lib.equss_vit_forward.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz,
+                                      c_int, c_int, c_int, c_vp]
+    lib.equss_expand_head.restype = c_int
+    lib.equss_expand_head.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]
+
+
+def load_library():
+    """dlopen libequss_hip.so (once) and declare every prototype.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise EqussError(
+                    f"{LIB_PATH} is not built. Run `python __graft_entry__.py build` (hipcc, gfx950). "
+                    "This package has no CPU or eager fallback.")
+            lib = ctypes.CDLL(LIB_PATH)
+            for sym in EXPORTED_SYMBOLS:
+                if not hasattr(lib, sym):
+                    raise EqussError(f"{LIB_PATH} does not export {sym}")
+            _declare(lib)
+            if lib.equss_abi_version() != 1:
+                raise EqussError("libequss_hip.so ABI version mismatch")
+            _lib = lib
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        msg = load_library().equss_last_error().decode("utf-8", "replace")
+        if rc in (2, 3, 4):
+            raise ValueError(f"{what}: {msg} (code {rc})")
+        raise EqussError(f"{what}: {msg} (code {rc})")
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise EqussError("the EQUSS HIP path needs tensors on a ROCm device (no CPU fallback exists)")
+
+
+_ws_cache = {}
+
+
+def _workspace(device, nbytes, tag):
+    """A per-(device, tag) scratch tensor that only grows; 256-byte aligned by the caching allocator."""
+    key = (device, tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+# ------------------------------------------------------------------------------------------------
+# Product quantisation
+# ------------------------------------------------------------------------------------------------
+def pq_assign(code_rows, codebooks, normalize="l2", gather_normalized=False, want_zq=True, want_loss=True):
+    """code_rows (rows, num_pq*d) fp32 (row stride may exceed the width), codebooks (num_pq, K, d) fp32.
+    Returns idx (num_pq, rows) int64, zq (rows, num_pq*d) fp32 or None, loss_sum (num_pq,) fp32 or None."""
+    lib = load_library()
+    _need_cuda(code_rows, codebooks)
+    if code_rows.dtype != torch.float32 or codebooks.dtype != torch.float32:
+        raise ValueError("pq_assign computes in fp32: code and codebooks must be float32")
+    if normalize not in NORM_MODES:
+        raise ValueError(f"Unsupported normalize type {normalize}")
+    num_pq, k, d = codebooks.shape
+    rows, width = code_rows.shape
+    if width != num_pq * d or code_rows.stride(1) != 1:
+        raise ValueError(f"code has {width} channels, codebooks need {num_pq}x{d}")
+    codebooks = codebooks.contiguous()
+    dev = code_rows.device
+    idx = torch.empty((num_pq, rows), dtype=torch.int64, device=dev)
+    zq = torch.empty((rows, width), dtype=torch.float32, device=dev) if want_zq else None
+    loss = torch.empty((num_pq,), dtype=torch.float32, device=dev) if want_loss else None
+    if rows == 0:
+        if loss is not None:
+            loss.zero_()
+        return idx, zq, loss
+    nbytes = lib.equss_pq_workspace_bytes(rows, num_pq, k, d)
+    ws = _workspace(dev, nbytes, "pq")
+    rc = lib.equss_pq_assign(_ptr(code_rows), code_rows.stride(0), _ptr(codebooks), _ptr(idx), _ptr(zq),
+                             width, _ptr(loss), _ptr(ws), ws.numel(), rows, num_pq, k, d,
+                             NORM_MODES[normalize], int(bool(gather_normalized)), _stream(code_rows))
+    _check(rc, "equss_pq_assign")
+    return idx, zq, loss
+
+
+def pq_prob(code_rows, codebooks, normalize="l2", tau=1.0):
+    """softmax(-dist / tau) over the K codewords: (rows, num_pq*K) fp32."""
+    lib = load_library()
+    _need_cuda(code_rows, codebooks)
+    num_pq, k, d = codebooks.shape
+    rows, width = code_rows.shape
+    codebooks = codebooks.contiguous()
+    prob = torch.empty((rows, num_pq * k), dtype=torch.float32, device=code_rows.device)
+    if rows == 0:
+        return prob
+    nbytes = lib.equss_pq_workspace_bytes(rows, num_pq, k, d)
+    ws = _workspace(code_rows.device, nbytes, "pq")
+    rc = lib.equss_pq_prob(_ptr(code_rows), code_rows.stride(0), _ptr(codebooks), _ptr(prob), _ptr(ws), ws.numel(),
+                           rows, num_pq, k, d, NORM_MODES[normalize], 1.0 / float(tau), _stream(code_rows))
+    _check(rc, "equss_pq_prob")
+    return prob
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT building blocks
+# ------------------------------------------------------------------------------------------------
+def layernorm_bf16(x, gamma, beta, eps=1e-6, tokens_per_image=0, out=None, want_f32=False):
+    """x (rows, C) fp32 -> bf16 (rows_out, C); with tokens_per_image > 0 the CLS row of every image is dropped."""
+    lib = load_library()
+    _need_cuda(x, gamma, beta)
+    rows, c = x.shape
+    rows_out = rows if tokens_per_image <= 0 else rows - rows // tokens_per_image
+    if out is None:
+        out = torch.empty((rows_out, c), dtype=torch.bfloat16, device=x.device)
+    out_f32 = torch.empty((rows_out, c), dtype=torch.float32, device=x.device) if want_f32 else None
+    rc = lib.equss_layernorm_bf16(_ptr(x), x.stride(0), _ptr(gamma), _ptr(beta), _ptr(out), out.stride(0),
+                                  _ptr(out_f32), rows, c, int(tokens_per_image), float(eps), _stream(x))
+    _check(rc, "equss_layernorm_bf16")
+    return (out, out_f32) if want_f32 else out
+
+
+def gemm_bf16(a, w, bias, epilogue, out=None):
+    """out = epilogue(a @ w.T + bias); a (M,K) bf16, w (N,K) bf16, bias (N,) fp32 or None."""
+    lib = load_library()
+    _need_cuda(a, w, bias)
+    m, k = a.shape
+    n = w.shape[0]
+    if out is None:
+        dt = torch.float32 if epilogue in (EPI_F32, EPI_RESID_F32) else torch.bfloat16
+        if epilogue == EPI_RESID_F32:
+            raise ValueError("the residual epilogue accumulates into `out`; pass it")
+        out = torch.empty((m, n), dtype=dt, device=a.device)
+    rc = lib.equss_gemm_bf16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(out), out.stride(0),
+                             m, n, k, int(epilogue), _stream(a))
+    _check(rc, "equss_gemm_bf16")
+    return out
+
+
+def attention_bf16(qkv, batch, tokens, heads, scale, out=None):
+    """qkv (batch*tokens, 3*heads*64) bf16 -> (batch*tokens, heads*64) bf16."""
+    lib = load_library()
+    _need_cuda(qkv)
+    if out is None:
+        out = torch.empty((batch * tokens, heads * 64), dtype=torch.bfloat16, device=qkv.device)
+    rc = lib.equss_attention_bf16(_ptr(qkv), _ptr(out), batch, tokens, heads, float(scale), _stream(qkv))
+    _check(rc, "equss_attention_bf16")
+    return out
+
+
+def patch_tokens(img, w_patch, b_patch, cls, pos, patch):
+    """img (B,3,H,W) fp32 -> x (B*(1+n), C) fp32 = cat(cls, patch_embed(img)) + pos."""
+    lib = load_library()
+    _need_cuda(img, w_patch, b_patch, cls, pos)
+    b, _, h, w = img.shape
+    c = w_patch.shape[0]
+    n = (h // patch) * (w // patch)
+    x = torch.empty((b * (n + 1), c), dtype=torch.float32, device=img.device)
+    nbytes = lib.equss_patch_workspace_bytes(b, h, w, patch, c)
+    ws = _workspace(img.device, nbytes, "patch")
+    rc = lib.equss_patch_tokens(_ptr(img), _ptr(w_patch), _ptr(b_patch), _ptr(cls), _ptr(pos), _ptr(x), _ptr(ws),
+                                ws.numel(), b, h, w, patch, c, _stream(img))
+    _check(rc, "equss_patch_tokens")
+    return x
+
+
+class VitHandle:
+    """Device-resident bf16/fp32 weight set of one backbone plus the host-side EqussVit struct."""
+
+    def __init__(self, tensors, embed_dim, depth, heads, patch):
+        self.tensors = tensors  # keeps the device buffers alive
+        self.blocks = (VitBlockStruct * depth)()
+        for i in range(depth):
+            for name, _ in VitBlockStruct._fields_:
+                setattr(self.blocks[i], name, tensors[f"blocks.{i}.{name}"].data_ptr())
+        self.struct = VitStruct(embed_dim, depth, heads, patch,
+                                tensors["patch_w"].data_ptr(), tensors["patch_b"].data_ptr(),
+                                tensors["cls"].data_ptr(), tensors["norm_g"].data_ptr(),
+                                tensors["norm_b"].data_ptr(), self.blocks)
+        self.embed_dim, self.depth, self.heads, self.patch = embed_dim, depth, heads, patch
+
+
+def vit_forward(handle, img, pos, feat_bf16=None, ld_feat=None, want_f32=False):
+    """Patch features of ``img`` (B,3,H,W) fp32: returns feat (B*n, C) bf16 view (and fp32 if asked)."""
+    lib = load_library()
+    _need_cuda(img, pos)
+    b, _, h, w = img.shape
+    c = handle.embed_dim
+    n = (h // handle.patch) * (w // handle.patch)
+    if feat_bf16 is None:
+        feat_bf16 = torch.empty((b * n, c), dtype=torch.bfloat16, device=img.device)
+    ld = feat_bf16.stride(0) if ld_feat is None else ld_feat
+    feat_f32 = torch.empty((b * n, c), dtype=torch.float32, device=img.device) if want_f32 else None
+    nbytes = lib.equss_vit_workspace_bytes(ctypes.byref(handle.struct), b, h, w)
+    ws = _workspace(img.device, nbytes, "vit")
+    rc = lib.equss_vit_forward(ctypes.byref(handle.struct), _ptr(img), _ptr(pos), _ptr(feat_bf16), ld, _ptr(feat_f32),
+                               _ptr(ws), ws.numel(), b, h, w, _stream(img))
+    _check(rc, "equss_vit_forward")
+    return (feat_bf16, feat_f32) if want_f32 else feat_bf16
+
+
+def expand_head(fh, w2a, b2a, w_cat, b_cat, out_dim):
+    """fh (rows, 2C) bf16 with the features in columns [0,C): returns code (rows, D) fp32."""
+    lib = load_library()
+    _need_cuda(fh, w2a, b2a, w_cat, b_cat)
+    rows, c2 = fh.shape
+    code = torch.empty((rows, out_dim), dtype=torch.float32, device=fh.device)
+    rc = lib.equss_expand_head(_ptr(fh), _ptr(w2a), _ptr(b2a), _ptr(w_cat), _ptr(b_cat), _ptr(code), rows, c2 // 2,
+                               out_dim, _stream(fh))
+    _check(rc, "equss_expand_head")
+    return code

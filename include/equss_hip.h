@@ -1,0 +1,171 @@
+/*
+ * equss_hip.h - C ABI of the MI355X (gfx950) EQUSS hot-path library (libequss_hip.so).
+ *
+ * The reference (pitlover/Expand-and-Quantize-for-Unsupervised-Semantic-Segmentation) is pure
+ * Python: its "operator interface" for this path is the forward() of a handful of nn.Modules that
+ * call stock ATen ops.  Each entry point below replaces the op sequence of one of those forward()s
+ * and cites it.  The Python modules that mirror the reference classes bind these symbols with
+ * ctypes; nothing here depends on PyTorch.
+ *
+ * Conventions
+ *  - Every pointer is a DEVICE pointer on the current HIP device unless noted; the caller owns all
+ *    memory (inputs, outputs, workspaces); the library allocates nothing and frees nothing.
+ *  - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns
+ *    without synchronising the host.
+ *  - Return value: 0 = success; > 0 = EQUSS_E_* argument/shape error (nothing was launched);
+ *    < 0 = minus the hipError_t of a failed launch.  equss_last_error() gives a message for the
+ *    calling thread.  No C++ exception and no abort crosses this boundary.
+ *  - Token-major layout: activations are (rows, channels) row-major with rows = batch * tokens;
+ *    this is the reference's (b, C, h, w) tensor viewed as (b, h, w, C).
+ */
+#ifndef EQUSS_HIP_H
+#define EQUSS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EQUSS_ABI_VERSION 1
+
+enum {
+    EQUSS_OK = 0,
+    EQUSS_E_NULL = 1,        /* a required pointer is NULL */
+    EQUSS_E_SHAPE = 2,       /* a dimension is non-positive or violates a divisibility rule */
+    EQUSS_E_UNSUPPORTED = 3, /* valid request that no kernel instance covers */
+    EQUSS_E_ALIGN = 4,       /* pointer or leading dimension not aligned as required */
+    EQUSS_E_WORKSPACE = 5    /* workspace smaller than the matching *_workspace_bytes() */
+};
+
+/* normalisation applied to z rows and codebook rows before the distance
+ * (model/dino_pqgo.py:613-640, model/quantizer.py:120-138) */
+enum { EQUSS_NORM_NONE = 0, EQUSS_NORM_L2 = 1, EQUSS_NORM_ZSCORE = 2 };
+
+/* epilogues of equss_gemm_bf16 */
+enum {
+    EQUSS_EPI_BF16 = 0,       /* out_bf16 = acc + bias                                      */
+    EQUSS_EPI_GELU_BF16 = 1,  /* out_bf16 = gelu_erf(acc + bias)   (vision_transformer.py:58-60) */
+    EQUSS_EPI_RELU_BF16 = 2,  /* out_bf16 = relu(acc + bias)       (dino_pqgo.py:108-112)   */
+    EQUSS_EPI_F32 = 3,        /* out_f32  = acc + bias                                      */
+    EQUSS_EPI_RESID_F32 = 4   /* out_f32 += acc + bias  (residual, vision_transformer.py:110-111) */
+};
+
+int equss_abi_version(void);
+const char* equss_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Product-quantisation assign.
+ * Replaces ProductQuantizerWrapper.forward + Codebook.forward (model/dino_pqgo.py:745-776,
+ * :579-705) and the same core in model/quantizer.py:105-189, :383-542, :587-611:
+ *   per sub-space p and row r:  zn = normalise(code[r, p*d:(p+1)*d]);  cn = normalise(codebook[p])
+ *   dist[k] = (sum zn^2 + sum cn[k]^2) - 2 * <zn, cn[k]>;   idx = first arg-min over k
+ *   emb = (gather_normalized ? cn : codebook[p])[idx];      zq = zn + (emb - zn)
+ *   loss_sum[p] = sum over rows and d of (emb - zn)^2        (the mse numerator of :685-686)
+ * All arithmetic is fp32; indices are int64 as torch.argmin returns them.
+ *
+ *   code       (rows, num_pq*d) fp32, leading dimension ld_code (elements, multiple of 4)
+ *   codebooks  (num_pq, K, d) fp32 contiguous raw embedding weights
+ *   idx        (num_pq, rows) int64 out
+ *   zq         (rows, num_pq*d) fp32 out, leading dimension ld_zq; may be NULL
+ *   loss_sum   (num_pq) fp32 out; may be NULL
+ *   workspace  equss_pq_workspace_bytes() bytes, 256-byte aligned
+ * Supported: d in {16,32,64,128}; K a multiple of 32, K <= 16*32*(128/d).
+ * ------------------------------------------------------------------------------------------- */
+size_t equss_pq_workspace_bytes(int rows, int num_pq, int K, int d);
+int equss_pq_assign(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
+                    float* zq, int64_t ld_zq, float* loss_sum, void* workspace, size_t workspace_bytes,
+                    int rows, int num_pq, int K, int d, int normalize, int gather_normalized,
+                    void* stream);
+
+/* softmax(-dist / tau) over the K codewords of every sub-space: the `distance_prob` tensor of
+ * model/dino_pqgo.py:655,:699,:774 (and quantizer.py:151,:468 with tau = 1).
+ *   prob (rows, num_pq*K) fp32 out. */
+int equss_pq_prob(const float* code, int64_t ld_code, const float* codebooks, float* prob,
+                  void* workspace, size_t workspace_bytes, int rows, int num_pq, int K, int d,
+                  int normalize, float inv_tau, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Building blocks of the ViT / head forward (exported so each can be parity-tested alone).
+ * ------------------------------------------------------------------------------------------- */
+
+/* LayerNorm over the last dim, fp32 in -> bf16 out (nn.LayerNorm eps=1e-6,
+ * model/dino/vision_transformer.py:98,:102,:160,:271).
+ *   x (rows, C) fp32 with leading dimension ld_x; out (rows_out, C) bf16 with leading dimension
+ *   ld_out.  If tokens_per_image > 0 the first token of every image (CLS) is dropped on output:
+ *   input row b*tokens_per_image + 1 + t goes to output row b*(tokens_per_image-1) + t
+ *   (model/dino/dino_featurizer.py:80-81).  out_f32 (same indexing, leading dimension C) may be
+ *   NULL; when given it receives the un-rounded fp32 result as well. */
+int equss_layernorm_bf16(const float* x, int64_t ld_x, const float* gamma, const float* beta,
+                         void* out_bf16, int64_t ld_out, float* out_f32, int rows, int C,
+                         int tokens_per_image, float eps, void* stream);
+
+/* C = A * W^T + bias with bf16 operands, fp32 MFMA accumulation and a fused epilogue
+ * (nn.Linear / 1x1 nn.Conv2d: vision_transformer.py:81,:89,:59,:62; dino_pqgo.py:104-112,:127-128).
+ *   A (M, K) bf16, leading dimension lda;  W (N, K) bf16 (PyTorch [out, in] layout), ldw;
+ *   bias (N) fp32 or NULL;  out (M, N) bf16 or fp32 by epilogue, leading dimension ldo.
+ * Requires N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W. */
+int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                    void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream);
+
+/* Multi-head self-attention softmax(q k^T * scale) v without materialising the (N x N) matrix
+ * (vision_transformer.py:81-88; the attention matrix it returns is discarded by
+ * dino_featurizer.py:76-80).
+ *   qkv (B*N, 3*H*64) bf16: the qkv Linear's output, columns ordered [3][H][64] (:81);
+ *   out (B*N, H*64) bf16: heads re-interleaved as :88 does.  head_dim is fixed at 64. */
+int equss_attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, void* stream);
+
+/* Patch embedding + CLS + position embedding (vision_transformer.py:130-133,:200-211).
+ *   img (B,3,H,W) fp32;  w_patch (C, 3*P*P) bf16;  b_patch (C) fp32;  cls (C) fp32;
+ *   pos (1 + (H/P)*(W/P), C) fp32 already resized to this grid (:178-198 is input-independent,
+ *   the host computes it once per image size);  x (B*(1+n), C) fp32 out.
+ *   workspace: equss_patch_workspace_bytes() bytes. */
+size_t equss_patch_workspace_bytes(int B, int H, int W, int P, int C);
+int equss_patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls,
+                       const float* pos, float* x, void* workspace, size_t workspace_bytes,
+                       int B, int H, int W, int P, int C, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Whole-path entry points.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct EqussVitBlock {
+    const float* ln1_g; const float* ln1_b;
+    const void* qkv_w;  const float* qkv_b;   /* (3C, C) bf16, (3C) fp32 */
+    const void* proj_w; const float* proj_b;  /* (C, C) */
+    const float* ln2_g; const float* ln2_b;
+    const void* fc1_w;  const float* fc1_b;   /* (4C, C) */
+    const void* fc2_w;  const float* fc2_b;   /* (C, 4C) */
+} EqussVitBlock;
+
+typedef struct EqussVit {
+    int32_t embed_dim, depth, heads, patch;    /* C, 12, C/64, 8 or 16 */
+    const void* patch_w; const float* patch_b; /* (C, 3*P*P) bf16, (C) fp32 */
+    const float* cls;                          /* (C) fp32 */
+    const float* norm_g; const float* norm_b;  /* final LayerNorm */
+    const EqussVitBlock* blocks;               /* HOST array of `depth` entries */
+} EqussVit;
+
+/* DinoFeaturizer.forward (model/dino/dino_featurizer.py:64-83) = prepare_tokens + all blocks +
+ * final norm + drop CLS (vision_transformer.py:227-239 with n=1).
+ *   vit: HOST struct of device pointers;  pos: as equss_patch_tokens;
+ *   feat_bf16 (B*n, C) bf16 out with leading dimension ld_feat (>= C, multiple of 8);
+ *   feat_f32 (B*n, C) fp32 out or NULL.  n = (H/P)*(W/P). */
+size_t equss_vit_workspace_bytes(const EqussVit* vit, int B, int H, int W);
+int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, void* feat_bf16,
+                      int64_t ld_feat, float* feat_f32, void* workspace, size_t workspace_bytes,
+                      int B, int H, int W, void* stream);
+
+/* Expansion head (model/dino_pqgo.py:104-112,:127-128):
+ *   code = W1 f + b1 + W2b relu(W2a f + b2a) + b2b, evaluated as two GEMMs:
+ *   h = relu(f W2a^T + b2a) written beside f, then code = [f | h] [W1 | W2b]^T + (b1 + b2b).
+ *   fh (rows, 2C) bf16: columns [0,C) hold f on entry, [C,2C) are overwritten with h;
+ *   w2a (C, C) bf16; b2a (C) fp32; w_cat (D, 2C) bf16 = [W1 | W2b]; b_cat (D) fp32 = b1 + b2b;
+ *   code (rows, D) fp32 out. */
+int equss_expand_head(void* fh, const void* w2a, const float* b2a, const void* w_cat,
+                      const float* b_cat, float* code, int rows, int C, int D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQUSS_HIP_H */

@@ -1,0 +1,90 @@
+"""Shared fixtures.  Tests marked ``gpu`` need a real MI355X and call the HIP kernels through the
+C ABI; everything else runs on CPU.  The oracle (oracle/equss_oracle.py) is the checker, never the
+thing under test on the GPU side."""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+PKG_NAME = "expand-and-quantize-for-unsupervised-semantic-segmentation_amd"
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a ROCm GPU (MI355X); runs the HIP kernels")
+
+
+@pytest.fixture(scope="session")
+def pkg():
+    return importlib.import_module(PKG_NAME)
+
+
+@pytest.fixture(scope="session")
+def native(pkg):
+    return importlib.import_module(PKG_NAME + ".native")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    return importlib.import_module("equss_oracle")
+
+
+@pytest.fixture(scope="session")
+def manifest():
+    with open(os.path.join(GOLDEN, "manifest.json")) as f:
+        return json.load(f)
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return load_golden
+
+
+@pytest.fixture(scope="session")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no ROCm device")
+    return torch.device("cuda", 0)
+
+
+def regen_pq_case(meta, scale=1.0):
+    """Rebuild the seeded inputs of a g4a/g6* fixture exactly as oracle/gen_golden.py drew them."""
+    n_rows, dim, num_pq, k, seed = (int(v) for v in meta)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    rows = torch.from_numpy((float(scale) * rng.standard_normal((n_rows, dim))).astype(np.float32))
+    books = torch.stack([torch.from_numpy(rng.uniform(-1.0 / k, 1.0 / k, size=(k, dim // num_pq)).astype(np.float32))
+                         for _ in range(num_pq)])
+    return rows, books
+
+
+# An fp32 distance carries ~1e-7 of rounding noise whose sign depends on the summation order, which
+# differs between MKL's sgemm, the MFMA fma chain and any other correct fp32 evaluation.  Two
+# codewords closer than this (in exact arithmetic) may legitimately swap.
+NEAR_TIE_GAP = 2e-6
+
+
+def assert_index_parity(got, want, gap64, what=""):
+    """Indices must be identical wherever the exact top-2 gap exceeds NEAR_TIE_GAP; the remaining
+    near-ties are counted and must stay a tiny fraction."""
+    got = np.asarray(got).astype(np.int64)
+    want = np.asarray(want).astype(np.int64)
+    gap = np.asarray(gap64)
+    assert got.shape == want.shape == gap.shape, (got.shape, want.shape, gap.shape)
+    diff = got != want
+    bad = diff & (gap > NEAR_TIE_GAP)
+    assert not bad.any(), f"{what}: {int(bad.sum())} index mismatches outside near-ties (of {got.size})"
+    near = int(diff.sum())
+    assert near <= max(2, got.size // 10000), f"{what}: {near} near-tie flips of {got.size}"
+    return near
