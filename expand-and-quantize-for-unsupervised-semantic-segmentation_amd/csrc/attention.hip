@@ -1,0 +1,240 @@
+// Multi-head self-attention for head_dim 64 on gfx950, flash style: softmax(q k^T * scale) v with the
+// (N x N) matrix never leaving registers.  Replaces Attention.forward's
+// q @ k^T -> softmax -> @ v -> transpose/reshape (model/dino/vision_transformer.py:81-88); the
+// attention matrix that forward also returns is discarded by its only caller on this path
+// (model/dino/dino_featurizer.py:76-80), so it is never written.
+//
+// One workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32 queries and walks
+// the keys in tiles of 64.
+//  * K and V tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (two stages; the next tile is in
+//    flight while the current one is on the matrix pipe).  K is chunk-swizzled for conflict-free
+//    ds_read_b128; V is swizzled for ds_read_b64_tr_b16, the transposing LDS read that turns
+//    row-major V into the k-contiguous fragment the MFMA wants.
+//  * S^T = K Q^T with v_mfma_f32_32x32x16_bf16, so a lane owns ONE query and 32 of the tile's 64
+//    scores: the row max / row sum are in-lane scans plus one cross-half shuffle.
+//  * The S^T accumulators, exponentiated and packed to bf16, are already the B operand of
+//    O^T = V^T P^T (rows of S^T are the summed index), so P never touches LDS.
+//  * Online softmax in fp32 (exp2 with the scale folded in); O is rescaled per tile.
+//  * Workgroup ids are remapped so the query blocks of one (image, head) run on one XCD and share
+//    its K/V in that XCD's L2.
+#include "equss_common.h"
+
+namespace {
+
+constexpr int HD = 64;          // head dim
+constexpr int QW = 32;          // queries per wave
+constexpr int QB = 128;         // queries per workgroup
+constexpr int KV = 64;          // keys per tile
+constexpr int kTile = KV * HD * 2;      // 8 KiB per K or V tile
+constexpr int kStage = 2 * kTile;       // K + V
+
+struct AttnArgs {
+    const u16* qkv; u16* out;
+    int B, N, H, nqb, ntiles;
+    float c;  // scale * log2(e)
+};
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const void __attribute__((address_space(1)))*)gsrc,
+        (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
+    typedef short s16x4 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
+}
+
+__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 31, lh = lane >> 5;
+
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + slot;
+    const int bh = logical / a.nqb, qb = logical % a.nqb;
+    const int b = bh / a.H, h = bh % a.H;
+    const int C = a.H * HD;
+    const size_t ld = (size_t)3 * C;
+    const u16* base = a.qkv + (size_t)b * a.N * ld + h * HD;  // q of token 0 of this (image, head)
+
+    // ---- Q fragments (B operand): lane (query lr, half lh) holds q[16 s + 8 lh + 0..7] -----------
+    int qrow = qb * QB + wave * QW + lr;
+    const bool q_valid = qrow < a.N;
+    if (!q_valid) qrow = a.N - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+        qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + 16 * s + 8 * lh);
+
+    // ---- K/V staging plan: 8 pieces of 8 rows per tile and operand, waves take pieces w, w + 4 ---
+    int st_row[2];
+    int st_kchunk[2], st_vchunk[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (wave + 4 * i) * 8 + (lane >> 3);
+        st_row[i] = row;
+        st_kchunk[i] = (lane & 7) ^ ((row >> 1) & 7);
+        st_vchunk[i] = (lane & 7) ^ (((row >> 1) & 1) << 2);
+    }
+    auto stage = [&](int buf, int t) {
+        char* sb = smem + buf * kStage;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int key = t * KV + st_row[i];
+            if (key > a.N - 1) key = a.N - 1;  // masked in the softmax; keeps V finite
+            const u16* src = base + (size_t)key * ld;
+            glds16(src + C + st_kchunk[i] * 8, sb + (wave + 4 * i) * 1024);
+            glds16(src + 2 * C + st_vchunk[i] * 8, sb + kTile + (wave + 4 * i) * 1024);
+        }
+    };
+
+    // ---- per-lane LDS read offsets -------------------------------------------------------------
+    // K (A operand of S^T): row lr (+32 for the second key tile), chunk 2 s + lh, swizzle (row>>1)&7.
+    int k_off[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) k_off[s] = lr * 128 + (((2 * s + lh) ^ ((lr >> 1) & 7)) * 16);
+    // V through the transposing read: 16-lane group G = lane>>4 covers d columns 16 (G&1) .. +15 and
+    // the keys of half lh = G>>1; lane 4 q + p of the group addresses key row q, columns 4 p .. 4 p + 3.
+    const int vq = (lane >> 2) & 3, vp = lane & 3, vg = (lane >> 4) & 1;
+    const int vsw = ((vq >> 1) & 1) << 2;
+    int v_off[2];  // per 32-wide d tile
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+        v_off[dt] = (4 * lh + vq) * 128 + (((4 * dt + 2 * vg + (vp >> 1)) ^ vsw) * 16) + (vp & 1) * 8;
+
+    f32x16 o0 = {0.f}, o1 = {0.f};  // O^T: d tile 0 / 1, lane = query
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
+    float m_run = -__builtin_inff();
+    float l_run = 0.f;
+    const float c = a.c;
+
+    stage(0, 0);
+    for (int t = 0; t < a.ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 1 < a.ntiles) stage((t + 1) & 1, t + 1);
+        const char* kb = smem + (t & 1) * kStage;
+        const char* vb = kb + kTile;
+
+        // ---- S^T = K Q^T for the two 32-key tiles --------------------------------------------
+        f32x16 s0, s1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb + k_off[s]);
+            const bf16x8 kc = *reinterpret_cast<const bf16x8*>(kb + 32 * 128 + k_off[s]);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, qf[s], s1, 0, 0, 0);
+        }
+        // register r of tile u <-> key  t*64 + 32 u + (r&3) + 8 (r>>2) + 4 lh
+        if ((t + 1) * KV > a.N) {
+            const int kbase = t * KV + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kbase + (r & 3) + 8 * (r >> 2);
+                if (key >= a.N) s0[r] = -__builtin_inff();
+                if (key + 32 >= a.N) s1[r] = -__builtin_inff();
+            }
+        }
+        // ---- online softmax ------------------------------------------------------------------
+        float mloc = s0[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s0[r]);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s1[r]);
+        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
+        const float m_new = fmaxf(m_run, mloc);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
+            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+
+        // ---- O^T += V^T P^T: P fragments straight from the S^T registers ----------------------
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                union { bf16x8 v; uint32_t w[4]; } pf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float lo = u == 0 ? s0[8 * sp + 2 * j] : s1[8 * sp + 2 * j];
+                    const float hi = u == 0 ? s0[8 * sp + 2 * j + 1] : s1[8 * sp + 2 * j + 1];
+                    pf.w[j] = equss::pack_bf16(lo, hi);
+                }
+                const int krow = (32 * u + 16 * sp) * 128;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    union { bf16x8 v; bf16x4 hlf[2]; } vf;
+                    vf.hlf[0] = ds_read_tr16(vb + krow + v_off[dt]);
+                    vf.hlf[1] = ds_read_tr16(vb + krow + 8 * 128 + v_off[dt]);
+                    if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o0, 0, 0, 0);
+                    else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o1, 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- normalise and store: lane (query, half) holds d = 32 dt + 8 g + 4 lh + 0..3 -----------
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (q_valid) {
+        u16* orow = a.out + ((size_t)b * a.N + qrow) * C + h * HD;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float x0 = (dt == 0 ? o0[4 * g + 0] : o1[4 * g + 0]) * inv;
+                const float x1 = (dt == 0 ? o0[4 * g + 1] : o1[4 * g + 1]) * inv;
+                const float x2 = (dt == 0 ? o0[4 * g + 2] : o1[4 * g + 2]) * inv;
+                const float x3 = (dt == 0 ? o0[4 * g + 3] : o1[4 * g + 3]) * inv;
+                uint2 pk;
+                pk.x = equss::pack_bf16(x0, x1);
+                pk.y = equss::pack_bf16(x2, x3);
+                *reinterpret_cast<uint2*>(orow + 32 * dt + 8 * g + 4 * lh) = pk;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace equss {
+
+int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s) {
+    if (!qkv || !out) return fail(EQUSS_E_NULL, "attention_bf16: null pointer argument");
+    if (B <= 0 || N <= 0 || H <= 0) return fail(EQUSS_E_SHAPE, "attention_bf16: B=%d N=%d H=%d must be positive", B, N, H);
+    if (((uintptr_t)qkv % 16) || ((uintptr_t)out % 16))
+        return fail(EQUSS_E_ALIGN, "attention_bf16: qkv and out must be 16-byte aligned");
+    AttnArgs a;
+    a.qkv = reinterpret_cast<const u16*>(qkv);
+    a.out = reinterpret_cast<u16*>(out);
+    a.B = B; a.N = N; a.H = H;
+    a.nqb = (N + QB - 1) / QB;
+    a.ntiles = (N + KV - 1) / KV;
+    a.c = scale * 1.4426950408889634f;
+    const long grid = (long)a.nqb * B * H;
+    if (grid > 0x7fffffffL) return fail(EQUSS_E_SHAPE, "attention_bf16: grid too large");
+    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(256), 2 * kStage, s, a);
+    return check_launch("attention_kernel");
+}
+
+}  // namespace equss
+
+extern "C" int equss_attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, void* stream) {
+    return equss::attention_bf16(qkv, out, B, N, H, scale, reinterpret_cast<hipStream_t>(stream));
+}

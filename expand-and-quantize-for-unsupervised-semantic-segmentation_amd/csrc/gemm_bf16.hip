@@ -1,0 +1,200 @@
+// C = A * W^T + bias on the gfx950 matrix cores: bf16 operands, fp32 accumulation, fused epilogue.
+//
+// Serves every nn.Linear / 1x1 nn.Conv2d of the path: qkv, proj, fc1, fc2
+// (model/dino/vision_transformer.py:81,:89,:59,:62), the patch embedding seen as a GEMM (:128-133)
+// and the expansion head (model/dino_pqgo.py:104-112,:127-128).  Both operands are K-contiguous
+// (activations are token-major, PyTorch weights are [out, in]), which is exactly what the MFMA
+// fragments want, so no transposition happens anywhere.
+//
+// Structure (one workgroup = 4 waves = one 128 x 128 output tile, K walked in steps of 64):
+//  * global_load_lds_dwordx4 moves both operand tiles HBM/L2 -> LDS without touching registers;
+//    two LDS stages, the loads of step k+1 are in flight while step k is on the matrix pipe.
+//  * The LDS image keeps 128-byte rows; 16-byte chunks are XOR-swizzled with (row>>1)&7 through the
+//    per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear), and the same XOR on the
+//    ds_read_b128 side makes every fragment read conflict-free.
+//  * v_mfma_f32_16x16x32_bf16 computes C^T tiles (W rows on the MFMA "A" side, activation rows on
+//    the "B" side): a lane then owns 4 consecutive output columns of one row, so the epilogue
+//    stores 8 B (bf16) or 16 B (fp32) per lane straight from registers.
+//  * Workgroup ids are remapped so that the tiles sharing an activation row-panel run back to back
+//    on one XCD and re-read it from that XCD's L2.
+#include "equss_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int kThreads = 256;
+
+struct GemmArgs {
+    const u16* A; int64_t lda;
+    const u16* W; int64_t ldw;
+    const float* bias;
+    void* out; int64_t ldo;
+    int M, N, K, ntn;  // ntn = N / BN
+};
+
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const void __attribute__((address_space(1)))*)gsrc,
+        (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+template <int EPI>
+__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    // XCD-aware bijective remap: ids that share (id % 8) share an XCD; give each XCD a contiguous
+    // run of logical tiles so neighbours in time share the activation panel in that XCD's L2.
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    const int m0 = (logical / g.ntn) * BM;
+    const int n0 = (logical % g.ntn) * BN;
+
+    // ---- staging plan: 4 LDS-DMA pieces per operand per wave, 8 rows x 128 B each -------------
+    const u16* a_src[4];
+    const u16* w_src[4];
+    int lds_row[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rowgrp = (i * 4 + wave) * 8;
+        const int row = rowgrp + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+        int am = m0 + row;
+        if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; their outputs are masked
+        a_src[i] = g.A + (size_t)am * g.lda + chunk * 8;
+        w_src[i] = g.W + (size_t)(n0 + row) * g.ldw + chunk * 8;
+        lds_row[i] = rowgrp * (BK * 2);
+    }
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * kStageBytes;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(a_src[i] + (size_t)kt * BK, base + lds_row[i]);
+            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + lds_row[i]);
+        }
+    };
+
+    // ---- fragment read offsets ----------------------------------------------------------------
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw = fr >> 1;  // (row >> 1) & 7 for row = 16 * x + fr
+    int a_off[2], w_off[2];  // byte offset of this lane's chunk for k sub-step 0 / 1 within a 16-row group
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int off = fr * (BK * 2) + (((4 * ks + fq) ^ sw) * 16);
+        a_off[ks] = (wave_m * 64) * (BK * 2) + off;
+        w_off[ks] = BM * BK * 2 + (wave_n * 64) * (BK * 2) + off;
+    }
+
+    f32x4 acc[4][4];  // [nt][mt], element j <-> output column n + j
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = g.K / BK;
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // tile kt has landed for every wave; buffer (kt+1)&1 is no longer read
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* base = smem + (kt & 1) * kStageBytes;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[4], wf[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                af[t] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + t * 16 * (BK * 2));
+                wf[t] = *reinterpret_cast<const bf16x8*>(base + w_off[ks] + t * 16 * (BK * 2));
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns out[m][n .. n+3] -------------------------------------------------
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wave_n * 64 + nt * 16 + fq * 4;
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wave_m * 64 + mt * 16 + fr;
+            if (m >= g.M) continue;
+            f32x4 v = acc[nt][mt];
+            v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+            if constexpr (EPI == EQUSS_EPI_GELU_BF16) {
+                v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+            }
+            if constexpr (EPI == EQUSS_EPI_RELU_BF16) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if constexpr (EPI == EQUSS_EPI_F32) {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n) = v;
+            } else if constexpr (EPI == EQUSS_EPI_RESID_F32) {
+                f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n);
+                f32x4 o = *p;
+                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
+                *p = o;
+            } else {
+                uint2 pk;
+                pk.x = equss::pack_bf16(v.x, v.y);
+                pk.y = equss::pack_bf16(v.z, v.w);
+                *reinterpret_cast<uint2*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n) = pk;
+            }
+        }
+    }
+}
+
+template <int EPI>
+int launch(const GemmArgs& g, hipStream_t s) {
+    const int grid = ((g.M + BM - 1) / BM) * g.ntn;
+    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(grid), dim3(kThreads), 2 * kStageBytes, s, g);
+    return equss::check_launch("gemm_bf16_kernel");
+}
+
+}  // namespace
+
+namespace equss {
+
+int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+              int M, int N, int K, int epilogue, hipStream_t s) {
+    if (!A || !W || !out) return fail(EQUSS_E_NULL, "gemm_bf16: null pointer argument");
+    if (M <= 0 || N <= 0 || K <= 0) return fail(EQUSS_E_SHAPE, "gemm_bf16: M=%d N=%d K=%d must be positive", M, N, K);
+    if (N % BN != 0 || K % BK != 0)
+        return fail(EQUSS_E_SHAPE, "gemm_bf16: N=%d must be a multiple of %d and K=%d of %d", N, BN, K, BK);
+    if (lda < K || ldw < K || ldo < N || (lda % 8) || (ldw % 8) || (ldo % 4) || ((uintptr_t)A % 16) ||
+        ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (bias && ((uintptr_t)bias % 16)))
+        return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
+    GemmArgs g;
+    g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
+    g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
+    g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.ntn = N / BN;
+    switch (epilogue) {
+        case EQUSS_EPI_BF16: return launch<EQUSS_EPI_BF16>(g, s);
+        case EQUSS_EPI_GELU_BF16: return launch<EQUSS_EPI_GELU_BF16>(g, s);
+        case EQUSS_EPI_RELU_BF16: return launch<EQUSS_EPI_RELU_BF16>(g, s);
+        case EQUSS_EPI_F32: return launch<EQUSS_EPI_F32>(g, s);
+        case EQUSS_EPI_RESID_F32: return launch<EQUSS_EPI_RESID_F32>(g, s);
+        default: return fail(EQUSS_E_UNSUPPORTED, "gemm_bf16: unknown epilogue %d", epilogue);
+    }
+}
+
+}  // namespace equss
+
+extern "C" int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                               void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
+    return equss::gemm_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, reinterpret_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,277 @@
+// The memory-bound pieces of the ViT forward (LayerNorm, patch gather, token assembly) and the
+// host-side sequencing of the whole DinoFeaturizer / expansion-head forward on one HIP stream.
+#include "equss_common.h"
+
+namespace equss {
+int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+              int M, int N, int K, int epilogue, hipStream_t s);
+int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s);
+}  // namespace equss
+
+namespace {
+
+using equss::group_sum;
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, the row lives in registers (C / 128 float2 per lane), two-pass
+// mean / variance like nn.LayerNorm (biased variance, eps inside the sqrt).
+// model/dino/vision_transformer.py:98,:102,:160 with eps = 1e-6 (:271).
+// ---------------------------------------------------------------------------------------------
+template <int VPL>  // float2 per lane: C = 128 * VPL
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ld_x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, u16* __restrict__ out,
+                                                        int64_t ld_out, float* __restrict__ out_f32, int rows,
+                                                        int tokens, float eps) {
+    constexpr int C = 128 * VPL;
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int orow = row;
+    if (tokens > 0) {
+        const int b = row / tokens, t = row % tokens;
+        if (t == 0) return;  // CLS token is dropped (model/dino/dino_featurizer.py:81)
+        orow = b * (tokens - 1) + t - 1;
+    }
+    const float2* xr = reinterpret_cast<const float2*>(x + (size_t)row * ld_x);
+    float2 v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i] = xr[i * 64 + lane];
+        s += v[i].x + v[i].y;
+    }
+    const float mean = group_sum<64>(s) * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        v[i].x -= mean; v[i].y -= mean;
+        q += v[i].x * v[i].x + v[i].y * v[i].y;
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<64>(q) * (1.0f / C) + eps);
+    const float2* g2 = reinterpret_cast<const float2*>(gamma);
+    const float2* b2 = reinterpret_cast<const float2*>(beta);
+    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)orow * ld_out);
+    float2* of = out_f32 ? reinterpret_cast<float2*>(out_f32 + (size_t)orow * C) : nullptr;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const float2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
+        const float y0 = v[i].x * rstd * g.x + bb.x;
+        const float y1 = v[i].y * rstd * g.y + bb.y;
+        o[i * 64 + lane] = equss::pack_bf16(y0, y1);
+        if (of) of[i * 64 + lane] = make_float2(y0, y1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Patch gather: img (B,3,H,W) fp32 -> rows of 3*P*P bf16 in the conv weight's (c, ph, pw) order,
+// so the 8x8/8 convolution of PatchEmbed (vision_transformer.py:128-133) is a plain GEMM.
+// One thread moves 8 horizontally adjacent pixels (32 B in, 16 B out).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ img, u16* __restrict__ cols,
+                                                           int B, int H, int W, int P, long items) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= items) return;
+    const int seg_per_row = P / 8;           // 8-pixel segments per patch row
+    const int kk = 3 * P * seg_per_row;      // segments per patch
+    const int gw = W / P, gh = H / P;
+    const long patch = gid / kk;
+    int rem = (int)(gid % kk);
+    const int c = rem / (P * seg_per_row); rem %= P * seg_per_row;
+    const int ph = rem / seg_per_row, sg = rem % seg_per_row;
+    const int b = (int)(patch / ((long)gh * gw));
+    const int pr = (int)(patch % ((long)gh * gw));
+    const int py = pr / gw, px = pr % gw;
+    const float* src = img + (((size_t)b * 3 + c) * H + (size_t)py * P + ph) * W + (size_t)px * P + sg * 8;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(src);
+    const f32x4 hi = *reinterpret_cast<const f32x4*>(src + 4);
+    uint4 o;
+    o.x = equss::pack_bf16(lo.x, lo.y); o.y = equss::pack_bf16(lo.z, lo.w);
+    o.z = equss::pack_bf16(hi.x, hi.y); o.w = equss::pack_bf16(hi.z, hi.w);
+    *reinterpret_cast<uint4*>(cols + (size_t)patch * (3 * P * P) + (size_t)c * P * P + ph * P + sg * 8) = o;
+}
+
+// x[b, 0] = cls + pos[0];  x[b, 1 + t] = patch[b, t] + pos[1 + t]   (vision_transformer.py:205-209)
+__global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __restrict__ patch,
+                                                              const float* __restrict__ cls,
+                                                              const float* __restrict__ pos, float* __restrict__ x,
+                                                              int n, int C, long items) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= items) return;
+    const int c4 = C / 4;
+    const long row = gid / c4;
+    const int col = (int)(gid % c4) * 4;
+    const int b = (int)(row / (n + 1)), t = (int)(row % (n + 1));
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + (size_t)t * C + col);
+    f32x4 v;
+    if (t == 0) v = *reinterpret_cast<const f32x4*>(cls + col);
+    else v = *reinterpret_cast<const f32x4*>(patch + ((size_t)b * n + t - 1) * C + col);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    *reinterpret_cast<f32x4*>(x + (size_t)row * C + col) = v;
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct PatchWs { u16* cols; float* tmp; size_t bytes; };
+PatchWs carve_patch(void* ws, int B, int H, int W, int P, int C) {
+    const size_t n = (size_t)B * (H / P) * (W / P);
+    PatchWs w;
+    char* base = reinterpret_cast<char*>(ws);
+    size_t off = 0;
+    w.cols = reinterpret_cast<u16*>(base + off); off += align256(n * 3 * P * P * 2);
+    w.tmp = reinterpret_cast<float*>(base + off); off += align256(n * C * 4);
+    w.bytes = off;
+    return w;
+}
+
+struct VitWs { float* x; u16* ln; u16* qkv; u16* att; u16* hid; void* patch; size_t patch_bytes; size_t bytes; };
+VitWs carve_vit(void* ws, int C, int B, int H, int W, int P) {
+    const size_t n = (size_t)(H / P) * (W / P);
+    const size_t rows = (size_t)B * (n + 1);
+    VitWs w;
+    char* base = reinterpret_cast<char*>(ws);
+    size_t off = 0;
+    w.x = reinterpret_cast<float*>(base + off); off += align256(rows * C * 4);
+    w.ln = reinterpret_cast<u16*>(base + off); off += align256(rows * C * 2);
+    w.qkv = reinterpret_cast<u16*>(base + off); off += align256(rows * 3 * C * 2);
+    w.att = reinterpret_cast<u16*>(base + off); off += align256(rows * C * 2);
+    w.hid = reinterpret_cast<u16*>(base + off); off += align256(rows * 4 * C * 2);
+    w.patch = base + off;
+    w.patch_bytes = carve_patch(nullptr, B, H, W, P, C).bytes;
+    off += w.patch_bytes;
+    w.bytes = off;
+    return w;
+}
+
+int check_image(int B, int H, int W, int P, int C) {
+    if (B <= 0 || H <= 0 || W <= 0) return equss::fail(EQUSS_E_SHAPE, "image batch %d x %d x %d must be positive", B, H, W);
+    if (P != 8 && P != 16) return equss::fail(EQUSS_E_UNSUPPORTED, "patch size %d (8 or 16 supported)", P);
+    if (H % P != 0 || W % P != 0)  // model/dino/dino_featurizer.py:70
+        return equss::fail(EQUSS_E_SHAPE, "image %d x %d is not divisible by the patch size %d", H, W, P);
+    if (C % 128 != 0 || C > 1024) return equss::fail(EQUSS_E_UNSUPPORTED, "embed dim %d (multiples of 128 up to 1024)", C);
+    return EQUSS_OK;
+}
+
+int layernorm(const float* x, int64_t ld_x, const float* gamma, const float* beta, void* out, int64_t ld_out,
+              float* out_f32, int rows, int C, int tokens, float eps, hipStream_t s) {
+    const int grid = (rows + 3) / 4;
+    u16* o = reinterpret_cast<u16*>(out);
+#define EQUSS_LN_CASE(V)                                                                                     \
+    case V:                                                                                                  \
+        hipLaunchKernelGGL(layernorm_kernel<V>, dim3(grid), dim3(256), 0, s, x, ld_x, gamma, beta, o, ld_out, \
+                           out_f32, rows, tokens, eps);                                                      \
+        break;
+    switch (C / 128) {
+        EQUSS_LN_CASE(1) EQUSS_LN_CASE(2) EQUSS_LN_CASE(3) EQUSS_LN_CASE(4)
+        EQUSS_LN_CASE(5) EQUSS_LN_CASE(6) EQUSS_LN_CASE(7) EQUSS_LN_CASE(8)
+        default: return equss::fail(EQUSS_E_UNSUPPORTED, "layernorm: C=%d", C);
+    }
+#undef EQUSS_LN_CASE
+    return equss::check_launch("layernorm_kernel");
+}
+
+int patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls, const float* pos,
+                 float* x, void* ws, int B, int H, int W, int P, int C, hipStream_t s) {
+    PatchWs w = carve_patch(ws, B, H, W, P, C);
+    const int n = (H / P) * (W / P);
+    const long items = (long)B * n * 3 * P * (P / 8);
+    hipLaunchKernelGGL(patch_gather_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, img, w.cols, B, H, W,
+                       P, items);
+    int rc = equss::check_launch("patch_gather_kernel");
+    if (rc) return rc;
+    rc = equss::gemm_bf16(w.cols, 3 * P * P, w_patch, 3 * P * P, b_patch, w.tmp, C, B * n, C, 3 * P * P, EQUSS_EPI_F32, s);
+    if (rc) return rc;
+    const long items2 = (long)B * (n + 1) * (C / 4);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((items2 + 255) / 256)), dim3(256), 0, s, w.tmp, cls, pos, x,
+                       n, C, items2);
+    return equss::check_launch("assemble_tokens_kernel");
+}
+
+}  // namespace
+
+extern "C" int equss_layernorm_bf16(const float* x, int64_t ld_x, const float* gamma, const float* beta,
+                                    void* out_bf16, int64_t ld_out, float* out_f32, int rows, int C,
+                                    int tokens_per_image, float eps, void* stream) {
+    if (!x || !gamma || !beta || !out_bf16) return equss::fail(EQUSS_E_NULL, "layernorm: null pointer argument");
+    if (rows <= 0 || C <= 0) return equss::fail(EQUSS_E_SHAPE, "layernorm: rows=%d C=%d must be positive", rows, C);
+    if (C % 128 != 0 || C > 1024) return equss::fail(EQUSS_E_UNSUPPORTED, "layernorm: C=%d (multiples of 128 up to 1024)", C);
+    if (tokens_per_image > 0 && rows % tokens_per_image != 0)
+        return equss::fail(EQUSS_E_SHAPE, "layernorm: rows=%d is not a multiple of tokens_per_image=%d", rows, tokens_per_image);
+    if (ld_x < C || ld_out < C || (ld_x % 2) || (ld_out % 2) || ((uintptr_t)x % 8) || ((uintptr_t)out_bf16 % 4) ||
+        ((uintptr_t)gamma % 8) || ((uintptr_t)beta % 8) || (out_f32 && ((uintptr_t)out_f32 % 8)))
+        return equss::fail(EQUSS_E_ALIGN, "layernorm: pointers must be 8-byte aligned and leading dimensions even");
+    return layernorm(x, ld_x, gamma, beta, out_bf16, ld_out, out_f32, rows, C, tokens_per_image, eps,
+                     reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t equss_patch_workspace_bytes(int B, int H, int W, int P, int C) {
+    if (B <= 0 || H <= 0 || W <= 0 || P <= 0 || C <= 0) return 0;
+    return carve_patch(nullptr, B, H, W, P, C).bytes;
+}
+
+extern "C" int equss_patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls,
+                                  const float* pos, float* x, void* workspace, size_t workspace_bytes, int B, int H,
+                                  int W, int P, int C, void* stream) {
+    if (!img || !w_patch || !b_patch || !cls || !pos || !x || !workspace)
+        return equss::fail(EQUSS_E_NULL, "patch_tokens: null pointer argument");
+    int rc = check_image(B, H, W, P, C);
+    if (rc) return rc;
+    if (((uintptr_t)img % 16) || ((uintptr_t)x % 16) || ((uintptr_t)pos % 16) || ((uintptr_t)cls % 16) ||
+        ((uintptr_t)workspace % 256))
+        return equss::fail(EQUSS_E_ALIGN, "patch_tokens: img/x/pos/cls must be 16-byte aligned, workspace 256-byte aligned");
+    if (workspace_bytes < equss_patch_workspace_bytes(B, H, W, P, C))
+        return equss::fail(EQUSS_E_WORKSPACE, "patch_tokens: workspace too small");
+    return patch_tokens(img, w_patch, b_patch, cls, pos, x, workspace, B, H, W, P, C, reinterpret_cast<hipStream_t>(stream));
+}
+
+extern "C" size_t equss_vit_workspace_bytes(const EqussVit* vit, int B, int H, int W) {
+    if (!vit || B <= 0 || H <= 0 || W <= 0 || vit->patch <= 0) return 0;
+    return carve_vit(nullptr, vit->embed_dim, B, H, W, vit->patch).bytes;
+}
+
+// prepare_tokens, then per block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))); final norm on
+// the last block's output with the CLS row dropped (vision_transformer.py:106-114,:227-239;
+// dino_featurizer.py:76-81).  ~8 launches per block, all on `stream`, no host synchronisation.
+extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, void* feat_bf16,
+                                 int64_t ld_feat, float* feat_f32, void* workspace, size_t workspace_bytes, int B,
+                                 int H, int W, void* stream) {
+    if (!vit || !img || !pos || !feat_bf16 || !workspace || !vit->blocks)
+        return equss::fail(EQUSS_E_NULL, "vit_forward: null pointer argument");
+    const int C = vit->embed_dim, P = vit->patch, heads = vit->heads;
+    int rc = check_image(B, H, W, P, C);
+    if (rc) return rc;
+    if (heads * 64 != C) return equss::fail(EQUSS_E_UNSUPPORTED, "vit_forward: head dim must be 64 (C=%d, heads=%d)", C, heads);
+    if (ld_feat < C || (ld_feat % 8) || ((uintptr_t)feat_bf16 % 16) || ((uintptr_t)workspace % 256))
+        return equss::fail(EQUSS_E_ALIGN, "vit_forward: feat must be 16-byte aligned with ld_feat a multiple of 8");
+    if (workspace_bytes < equss_vit_workspace_bytes(vit, B, H, W))
+        return equss::fail(EQUSS_E_WORKSPACE, "vit_forward: workspace of %zu bytes is smaller than the %zu required",
+                           workspace_bytes, equss_vit_workspace_bytes(vit, B, H, W));
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    VitWs w = carve_vit(workspace, C, B, H, W, P);
+    const int n = (H / P) * (W / P), N = n + 1, rows = B * N;
+    rc = patch_tokens(img, vit->patch_w, vit->patch_b, vit->cls, pos, w.x, w.patch, B, H, W, P, C, s);
+    if (rc) return rc;
+    const float scale = 0.125f;  // head_dim ** -0.5 with head_dim = 64 (vision_transformer.py:71-72)
+    for (int i = 0; i < vit->depth; ++i) {
+        const EqussVitBlock& k = vit->blocks[i];
+        if ((rc = layernorm(w.x, C, k.ln1_g, k.ln1_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))) return rc;
+        if ((rc = equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))) return rc;
+        if ((rc = equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))) return rc;
+        if ((rc = equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))) return rc;
+        if ((rc = layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))) return rc;
+        if ((rc = equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))) return rc;
+        if ((rc = equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))) return rc;
+    }
+    return layernorm(w.x, C, vit->norm_g, vit->norm_b, feat_bf16, ld_feat, feat_f32, rows, C, N, 1e-6f, s);
+}
+
+// code = [f | relu(f W2a^T + b2a)] [W1 | W2b]^T + (b1 + b2b)   (model/dino_pqgo.py:104-112,:127-128)
+extern "C" int equss_expand_head(void* fh, const void* w2a, const float* b2a, const void* w_cat, const float* b_cat,
+                                 float* code, int rows, int C, int D, void* stream) {
+    if (!fh || !w2a || !b2a || !w_cat || !b_cat || !code) return equss::fail(EQUSS_E_NULL, "expand_head: null pointer argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    u16* f = reinterpret_cast<u16*>(fh);
+    int rc = equss::gemm_bf16(f, 2 * C, w2a, C, b2a, f + C, 2 * C, rows, C, C, EQUSS_EPI_RELU_BF16, s);
+    if (rc) return rc;
+    return equss::gemm_bf16(f, 2 * C, w_cat, 2 * C, b_cat, code, D, rows, D, 2 * C, EQUSS_EPI_F32, s);
+}

@@ -150,8 +150,10 @@ def pq_assign(code_rows, codebooks, normalize="l2", gather_normalized=False, wan
         raise ValueError(f"Unsupported normalize type {normalize}")
     num_pq, k, d = codebooks.shape
     rows, width = code_rows.shape
-    if width != num_pq * d or code_rows.stride(1) != 1:
+    if width != num_pq * d:
         raise ValueError(f"code has {width} channels, codebooks need {num_pq}x{d}")
+    if code_rows.stride(1) != 1 or code_rows.stride(0) % 4 != 0 or code_rows.data_ptr() % 16 != 0:
+        code_rows = code_rows.contiguous()
     codebooks = codebooks.contiguous()
     dev = code_rows.device
     idx = torch.empty((num_pq, rows), dtype=torch.int64, device=dev)
@@ -176,6 +178,8 @@ def pq_prob(code_rows, codebooks, normalize="l2", tau=1.0):
     _need_cuda(code_rows, codebooks)
     num_pq, k, d = codebooks.shape
     rows, width = code_rows.shape
+    if code_rows.stride(1) != 1 or code_rows.stride(0) % 4 != 0 or code_rows.data_ptr() % 16 != 0:
+        code_rows = code_rows.contiguous()
     codebooks = codebooks.contiguous()
     prob = torch.empty((rows, num_pq * k), dtype=torch.float32, device=code_rows.device)
     if rows == 0:

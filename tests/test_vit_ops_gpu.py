@@ -1,0 +1,154 @@
+"""Each HIP building block of the ViT / head forward against a plain PyTorch fp32 reference of the
+same op on CPU (operands rounded to bf16 first where the kernel consumes bf16, so the comparison
+isolates the kernel's own arithmetic)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("shape", [(300, 256, 192), (128, 128, 64), (1, 384, 384), (1000, 1152, 384)])
+def test_gemm_exact_on_integer_data(epi, shape, native, dev):
+    """Small-integer operands make every product and partial sum exact in bf16/fp32, so any fragment
+    or layout mistake (swapped rows/cols, wrong k order, missed tail) shows up as a hard mismatch."""
+    m, n, k = shape
+    g = _rng(epi * 100 + m)
+    a = torch.from_numpy(g.integers(-3, 4, size=(m, k)).astype(np.float32))
+    w = torch.from_numpy(g.integers(-2, 3, size=(n, k)).astype(np.float32))
+    w[:, 0] += torch.arange(n, dtype=torch.float32) % 5          # asymmetric in n
+    a[:, 1] += (torch.arange(m, dtype=torch.float32) % 3)        # asymmetric in m
+    bias = torch.from_numpy(g.integers(-4, 5, size=(n,)).astype(np.float32))
+    ref = a @ w.t() + bias
+    if epi == 1:
+        ref = F.gelu(ref)
+    elif epi == 2:
+        ref = F.relu(ref)
+    out = None
+    if epi == 4:
+        base = torch.from_numpy(g.integers(-8, 9, size=(m, n)).astype(np.float32))
+        ref = base + ref
+        out = base.clone().to(dev)
+    got = native.gemm_bf16(_bf(a).to(dev), _bf(w).to(dev), bias.to(dev), epi, out=out)
+    torch.cuda.synchronize()
+    if epi in (3, 4):
+        assert got.dtype == torch.float32
+        assert torch.equal(got.cpu(), ref)
+    else:
+        assert got.dtype == torch.bfloat16
+        torch.testing.assert_close(got.cpu().float(), _bf(ref).float(), rtol=8e-3, atol=1e-6)
+
+
+def test_gemm_random_and_strided(native, dev):
+    g = _rng(5)
+    m, n, k = 777, 384, 1536
+    a = _bf(torch.from_numpy(g.standard_normal((m, k + 64)).astype(np.float32)))
+    w = _bf(torch.from_numpy((g.standard_normal((n, k)) / math.sqrt(k)).astype(np.float32)))
+    bias = torch.from_numpy(g.standard_normal(n).astype(np.float32))
+    a_dev = a.to(dev)
+    got = native.gemm_bf16(a_dev[:, :k], w.to(dev), bias.to(dev), 3)
+    ref = a[:, :k].double() @ w.double().t() + bias.double()
+    assert (got.cpu().double() - ref).abs().max() < 2e-4
+    got_nobias = native.gemm_bf16(a_dev[:, :k], w.to(dev), None, 3)
+    assert (got_nobias.cpu().double() - (ref - bias.double())).abs().max() < 2e-4
+
+
+def test_gemm_rejects_bad_shapes(native, dev):
+    a = torch.zeros(8, 64, dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ValueError):
+        native.gemm_bf16(a, torch.zeros(100, 64, dtype=torch.bfloat16, device=dev), None, 3)   # N % 128
+    with pytest.raises(ValueError):
+        native.gemm_bf16(a[:, :32], torch.zeros(128, 32, dtype=torch.bfloat16, device=dev), None, 3)  # K % 64
+
+
+@pytest.mark.parametrize("c", [384, 768])
+def test_layernorm(c, native, dev):
+    g = _rng(c)
+    x = torch.from_numpy((3 * g.standard_normal((10, c)) + 1.5).astype(np.float32))
+    gamma = torch.from_numpy((1 + 0.1 * g.standard_normal(c)).astype(np.float32))
+    beta = torch.from_numpy((0.1 * g.standard_normal(c)).astype(np.float32))
+    ref = F.layer_norm(x, (c,), gamma, beta, 1e-6)
+    out, out32 = native.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6, want_f32=True)
+    torch.testing.assert_close(out32.cpu(), ref, rtol=1e-5, atol=2e-6)
+    torch.testing.assert_close(out.cpu().float(), _bf(ref).float(), rtol=8e-3, atol=1e-6)
+    # CLS drop: 2 images x 5 tokens -> 8 rows
+    out = native.layernorm_bf16(x.to(dev), gamma.to(dev), beta.to(dev), 1e-6, tokens_per_image=5)
+    keep = [1, 2, 3, 4, 6, 7, 8, 9]
+    assert out.shape == (8, c)
+    torch.testing.assert_close(out.cpu().float(), _bf(ref[keep]).float(), rtol=8e-3, atol=1e-6)
+
+
+def _attention_ref(qkv, b, n, h):
+    q, k, v = qkv.double().reshape(b, n, 3, h, 64).permute(2, 0, 3, 1, 4)
+    att = ((q @ k.transpose(-2, -1)) * 0.125).softmax(dim=-1)
+    return (att @ v).transpose(1, 2).reshape(b * n, h * 64)
+
+
+@pytest.mark.parametrize("b,n,h", [(2, 65, 6), (1, 200, 2), (1, 1601, 1), (3, 64, 12), (1, 129, 6)])
+def test_attention_matches_fp64_reference(b, n, h, native, dev):
+    g = _rng(n + h)
+    qkv = _bf(torch.from_numpy(g.standard_normal((b * n, 3 * h * 64)).astype(np.float32)))
+    ref = _attention_ref(qkv, b, n, h)
+    out = native.attention_bf16(qkv.to(dev), b, n, h, 0.125)
+    torch.cuda.synchronize()
+    err = (out.cpu().double() - ref).abs()
+    assert err.max() < 2e-2, float(err.max())
+    assert err.mean() < 2e-3, float(err.mean())
+
+
+def test_attention_exact_layout_on_selector_data(native, dev):
+    """One-hot attention: every query matches exactly one key by a huge margin, so the output row
+    must equal that key's V row (bf16-exact).  Catches any key/query/d permutation mistake."""
+    b, n, h = 1, 150, 2
+    g = _rng(9)
+    perm = torch.from_numpy(g.permutation(n))
+    qkv = torch.zeros(n, 3, h, 64)
+    code = torch.from_numpy(g.choice([-1.0, 1.0], size=(n, 64)).astype(np.float32))  # near-orthogonal +-1 codes
+    for hh in range(h):
+        qkv[:, 1, hh] = code * 4                   # keys
+        qkv[:, 0, hh] = code[perm] * 4             # query i looks for key perm[i]
+        qkv[:, 2, hh] = torch.from_numpy(g.integers(-8, 9, size=(n, 64)).astype(np.float32))
+    out = native.attention_bf16(_bf(qkv.reshape(n, -1)).to(dev), b, n, h, 0.125).cpu().float().reshape(n, h, 64)
+    want = qkv[:, 2][perm]                          # (n, h, 64)
+    assert (out - want).abs().max() < 0.05
+
+
+def test_attention_rescale_branch_is_exercised(native, dev):
+    """A key far above the running max in a late tile forces the online-softmax rescale."""
+    b, n, h = 1, 300, 1
+    g = _rng(10)
+    qkv = torch.from_numpy(g.standard_normal((n, 3, 1, 64)).astype(np.float32)) * 0.5
+    qkv[7, 0, 0] = 0.0
+    qkv[7, 0, 0, :8] = 6.0
+    qkv[250, 1, 0, :8] = 6.0      # tile 3 holds the spike for query 7
+    qkv = _bf(qkv.reshape(n, -1))
+    ref = _attention_ref(qkv, b, n, h)
+    out = native.attention_bf16(qkv.to(dev), b, n, h, 0.125)
+    assert (out.cpu().double() - ref).abs().max() < 2e-2
+
+
+def test_patch_tokens(native, dev):
+    g = _rng(11)
+    b, hh, ww, p, c = 2, 48, 80, 8, 384
+    img = torch.from_numpy(g.standard_normal((b, 3, hh, ww)).astype(np.float32))
+    w = torch.from_numpy((0.07 * g.standard_normal((c, 3, p, p))).astype(np.float32))
+    bias = torch.from_numpy((0.05 * g.standard_normal(c)).astype(np.float32))
+    cls = torch.from_numpy(g.standard_normal(c).astype(np.float32))
+    n = (hh // p) * (ww // p)
+    pos = torch.from_numpy(g.standard_normal((n + 1, c)).astype(np.float32))
+    ref = F.conv2d(_bf(img).float(), _bf(w).float(), bias, stride=p).flatten(2).transpose(1, 2)
+    ref = torch.cat((cls.expand(b, 1, c), ref), dim=1) + pos
+    x = native.patch_tokens(img.to(dev), _bf(w.reshape(c, -1)).to(dev), bias.to(dev), cls.to(dev), pos.to(dev), p)
+    torch.testing.assert_close(x.cpu().reshape(b, n + 1, c), ref, rtol=1e-4, atol=1e-4)
