@@ -1,0 +1,80 @@
+"""Linear and cluster probes (model/evaluator.py:11-111) with the reference's parameter names
+(``linear_probe.{weight,bias}``, ``cluster_probe.clusters``).
+
+The probes sit next to the hot path (they consume its output inside the eval loop) but are not
+part of it: this module follows the reference's op sequence with stock device ops so that the
+wrapper's return tuple and losses are complete.  The (B, D, H, W) bilinear up-sampling of the
+D = 1024 feature map costs 420 MB fp32 per 320x320 image, so large batches are processed in
+slices of a few images to bound memory.
+"""
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+__all__ = ["UnSegEvaluator", "ClusterLookup"]
+
+
+class ClusterLookup(nn.Module):
+    def __init__(self, dim: int, n_classes: int):
+        super().__init__()
+        self.n_classes = n_classes
+        self.dim = dim
+        self.clusters = nn.Parameter(torch.randn(n_classes, dim))
+
+    def forward(self, x: torch.Tensor, alpha: Optional[float] = 2.0, log_probs: bool = False):
+        """evaluator.py:93-111 on a feature map already at the target resolution."""
+        normed_clusters = F.normalize(self.clusters, dim=1)
+        normed_features = F.normalize(x, dim=1)
+        inner = torch.einsum("bchw,nc->bnhw", normed_features, normed_clusters)
+        if alpha is None:
+            probs = F.one_hot(torch.argmax(inner, dim=1), self.n_classes).permute(0, 3, 1, 2).contiguous().to(torch.float32)
+        else:
+            probs = F.softmax(inner * alpha, dim=1)
+        loss = -torch.sum(probs * inner, dim=1).mean()
+        if log_probs:
+            return loss, F.log_softmax(inner * alpha, dim=1)
+        return loss, probs
+
+
+class UnSegEvaluator(nn.Module):
+    def __init__(self, embed_dim: int, num_classes: int, extra_classes: int = 0, num_pq: int = 1) -> None:
+        super().__init__()
+        self.num_classes = num_classes
+        self.linear_probe = nn.Conv2d(embed_dim, num_classes, kernel_size=1, stride=1)
+        self.cluster_probe = ClusterLookup(embed_dim, num_classes + extra_classes)
+        self.linear_loss = nn.CrossEntropyLoss()
+        self.slice_images = 4  # images per up-sampling slice in eval
+
+    def forward(self, out: torch.Tensor, img: torch.Tensor, label: Optional[torch.Tensor] = None,
+                is_crf: bool = False):
+        """evaluator.py:46-82 (is_crf=False).  Returns (linear_loss, linear_preds, cluster_loss, cluster_preds)."""
+        if is_crf:
+            raise NotImplementedError("dense-CRF post-processing (pydensecrf on the host) is outside this build")
+        assert label is not None
+        b = out.shape[0]
+        step = b if (self.training and torch.is_grad_enabled()) else self.slice_images
+        lin_logits, lin_preds, clu_preds, clu_inner = [], [], [], []
+        for s in range(0, b, step):
+            o = out[s:s + step]
+            if o.shape[-2:] != label.shape[-2:]:
+                o = F.interpolate(o, label.shape[-2:], mode="bilinear", align_corners=False)
+            logits = self.linear_probe(o)
+            lin_logits.append(logits)
+            lin_preds.append(logits.argmax(1))
+            # ClusterLookup with alpha=None: one-hot of the arg-max, loss = -mean(max inner product)
+            normed_clusters = F.normalize(self.cluster_probe.clusters, dim=1)
+            inner = torch.einsum("bchw,nc->bnhw", F.normalize(o, dim=1), normed_clusters)
+            top = inner.max(dim=1)
+            clu_preds.append(top.indices)
+            clu_inner.append(top.values)
+        linear_logits = torch.cat(lin_logits)
+        linear_preds = torch.cat(lin_preds)
+        cluster_preds = torch.cat(clu_preds)
+        cluster_loss = -torch.cat(clu_inner).mean()
+        label_flat = label.reshape(-1)
+        mask = torch.logical_and(label_flat >= 0, label_flat < self.num_classes)
+        logit_flat = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
+        linear_loss = self.linear_loss(logit_flat[mask], label_flat[mask]).mean()
+        return linear_loss, linear_preds, cluster_loss, cluster_preds
