@@ -1,0 +1,224 @@
+"""Benchmark of the EQUSS hot path on MI355X: images/s at 320x320 for DINO-ViT patch features ->
+expansion head -> product-quantisation assign (BASELINE.json's metric), one process per GPU.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one eval forward of DIONPQGO (ViT-S/8, D=1024, 8 sub-spaces x 256 codewords) over one
+synthetic batch already resident in HBM.  Images are independent, so ranks shard them with no
+data-path collective (weak scaling: the per-GPU batch is fixed).  Rank 0 prints one JSON line.
+
+Besides the contract fields the line carries
+  roofline      - the kernel class with the largest share of the step, priced against the dense
+                  bf16 MFMA peak, from HIP events recorded around every launch of a second pass of
+                  the same K steps (the timed pass itself runs without events);
+  roofline_pq   - the PQ-assign kernel against HBM bandwidth (and the fp32 rate that actually
+                  bounds an exact-fp32 search at K = 256);
+  kernels       - every kernel class: ms per step, launches, achieved rate;
+  cpu_baseline  - the CPU oracle (same algorithm, fp32, PyTorch CPU ops) timed on this node's host
+                  cores on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = "expand-and-quantize-for-unsupervised-semantic-segmentation_amd"
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_MFMA = 2.5e15     # dense, FLOP/s
+PEAK_HBM = 8.0e12           # B/s
+PEAK_FP32 = 157.3e12        # FLOP/s (vector = f32 MFMA rate)
+
+
+def algorithmic_work(cfg, batch, height, width):
+    """FLOPs (2 M N K, no recompute) and bytes per LAUNCH of each kernel class for one batch."""
+    from_cfg = cfg["model"]
+    c = {"vit_small": 384, "vit_base": 768}[from_cfg["pretrained"]["model_type"]]
+    p = from_cfg["pretrained"]["dino_patch_size"]
+    d_out = from_cfg["vq"]["embed_dims"][0]
+    k = from_cfg["vq"]["num_codebooks"][0]
+    num_pq = from_cfg["vq"]["num_pq"][0]
+    n = (height // p) * (width // p)
+    tokens = n + 1
+    rows = batch * tokens
+    w = {
+        "patch": {"flops": 2.0 * batch * n * (3 * p * p) * c},
+        "layernorm": {"bytes": rows * c * (4 + 2)},
+        "gemm_qkv": {"flops": 2.0 * rows * c * 3 * c},
+        "attention": {"flops": 4.0 * batch * tokens * tokens * c},
+        "gemm_proj": {"flops": 2.0 * rows * c * c},
+        "gemm_fc1": {"flops": 2.0 * rows * c * 4 * c},
+        "gemm_fc2": {"flops": 2.0 * rows * 4 * c * c},
+        "head_gemm1": {"flops": 2.0 * batch * n * c * c},
+        "head_gemm2": {"flops": 2.0 * batch * n * 2 * c * d_out},
+        "pq_prep": {"bytes": 2 * num_pq * k * (d_out // num_pq) * 4},
+        # read code + write z_q + write int64 indices; codebooks are L2/register resident
+        "pq_assign": {"bytes": batch * n * (2 * d_out * 4 + num_pq * 8), "flops": 2.0 * batch * n * d_out * k},
+    }
+    return w
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
+    ap.add_argument("--res", type=int, default=320)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU: the EQUSS path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")  # RCCL over xGMI on ROCm
+
+    pkg = importlib.import_module(PKG)
+    cfg = pkg.configs.S_CFG
+    state = pkg.synth.synth_pqgo_state(cfg, seed=1234)
+    model = pkg.build_model(cfg)
+    model.load_state_dict(state, strict=True)
+    model = model.to(dev).eval()
+    img = pkg.synth.synth_images(args.batch, args.res, args.res, seed=1 + rank).to(dev)
+
+    def step():
+        with torch.no_grad():
+            return model.model(img=img)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # ---- timed region: exactly K steps, no events, no host sync inside ------------------------
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    z_index = out[2][2]
+    assert z_index.shape[0] == cfg["model"]["vq"]["num_pq"][0] and z_index.dtype == torch.int64
+
+    # ---- same K steps again with a HIP event pair around every kernel-class launch ---------------
+    per_step_launches = 12 * 7 + 8
+    pkg.native.profile_enable(per_step_launches * args.steps + 64)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    profiled = time.perf_counter() - t1
+    prof = pkg.native.profile_read(reset=True)
+    pkg.native.profile_enable(0)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    work = algorithmic_work(cfg, args.batch, args.res, args.res)
+    traffic = {}
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            traffic = json.load(f)
+    kernels = {}
+    for name, (ms, launches) in prof.items():
+        if launches == 0:
+            continue
+        avg_s = ms / launches / 1e3
+        entry = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": launches / args.steps,
+                 "avg_launch_us": round(avg_s * 1e6, 2)}
+        if "flops" in work[name]:
+            entry["tflops"] = round(work[name]["flops"] / avg_s / 1e12, 2)
+        if "bytes" in work[name]:
+            entry["gbps"] = round(work[name]["bytes"] / avg_s / 1e9, 1)
+        kernels[name] = entry
+    dominant = max((k for k in kernels if "tflops" in kernels[k] and k != "pq_assign"),
+                   key=lambda k: kernels[k]["ms_per_step"])
+    dom = kernels[dominant]
+    roofline = {"kernel": dominant, "bound": "mfma", "achieved": dom["tflops"], "peak": PEAK_BF16_MFMA / 1e12,
+                "unit": "TFLOP/s", "frac": round(dom["tflops"] * 1e12 / PEAK_BF16_MFMA, 4),
+                "traffic": traffic.get(dominant), "avg_launch_us": dom["avg_launch_us"],
+                "share_of_step": round(dom["ms_per_step"] / sum(k["ms_per_step"] for k in kernels.values()), 3),
+                "profiled_ms_per_step": round(profiled / args.steps * 1e3, 3)}
+    pq = kernels["pq_assign"]
+    roofline_pq = {"kernel": "pq_assign", "bound": "hbm", "achieved": pq["gbps"], "peak": PEAK_HBM / 1e9,
+                   "unit": "GB/s", "frac": round(pq["gbps"] * 1e9 / PEAK_HBM, 4), "traffic": traffic.get("pq_assign"),
+                   "avg_launch_us": pq["avg_launch_us"], "fp32_tflops": pq["tflops"],
+                   "fp32_frac": round(pq["tflops"] * 1e12 / PEAK_FP32, 4)}
+    total_flops = sum(work[k]["flops"] * prof[k][1] / args.steps for k in work if "flops" in work[k] and prof[k][1])
+    ms_per_step = elapsed / args.steps * 1e3
+
+    cpu_baseline = None
+    if world == 1 and args.cpu_seconds > 0:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        oracle = importlib.import_module("equss_oracle")
+        cpu_img = pkg.synth.synth_images(4, args.res, args.res, seed=0)
+        torch.set_grad_enabled(False)
+        oracle.pqgo_forward(state, cpu_img, cfg)  # warm-up
+        best, runs, spent = float("inf"), 0, 0.0
+        while runs < 2 or (spent < args.cpu_seconds and runs < 8):
+            c0 = time.perf_counter()
+            oracle.pqgo_forward(state, cpu_img, cfg)
+            dt = time.perf_counter() - c0
+            best, runs, spent = min(best, dt), runs + 1, spent + dt
+        cpu_baseline = {"value": round(4.0 / best, 3), "unit": "images/s", "cores": torch.get_num_threads(),
+                        "kind": "port",
+                        "sample": f"model forward (ViT+head+PQ) on 4 images {args.res}x{args.res}, fp32, "
+                                  f"best of {runs} runs after 1 warm-up, {spent:.1f} s of CPU time"}
+
+    line = {
+        "metric": "images/sec (320x320) end-to-end fwd+PQ-assign",
+        "value": round(world * args.batch * args.steps / elapsed, 2),
+        "unit": "images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "bf16",
+        "data": "synthetic",
+        "config": {"workload": f"DINO ViT-S/8 + expansion head (D=1024) + 8-subspace PQ (K=256), "
+                               f"batch {args.batch} x {args.res}x{args.res} per GPU, bf16 ViT/head + fp32 PQ, eval forward",
+                   "per_gpu_batch": args.batch, "global_batch": args.batch * world, "resolution": args.res,
+                   "parallelism": f"dp{world} (images sharded, no data-path collective)"},
+        "model_tflops": round(total_flops / (elapsed / args.steps) / 1e12, 1),
+        "roofline": roofline,
+        "roofline_pq": roofline_pq,
+        "kernels": kernels,
+        "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(line))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

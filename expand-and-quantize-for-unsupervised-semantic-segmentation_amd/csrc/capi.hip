@@ -16,7 +16,60 @@ int fail(int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- profiling pool (host objects only; no device memory) ------------------------------------
+namespace {
+struct Pair { hipEvent_t a, b; int cls; };
+Pair* g_pairs = nullptr;
+int g_cap = 0, g_used = 0;
+bool g_on = false;
+}  // namespace
+
+bool prof_on() { return g_on && g_used < g_cap; }
+void prof_begin(int cls, hipStream_t s) {
+    g_pairs[g_used].cls = cls;
+    (void)hipEventRecord(g_pairs[g_used].a, s);
+}
+void prof_end(hipStream_t s) {
+    (void)hipEventRecord(g_pairs[g_used].b, s);
+    ++g_used;
+}
+
 }  // namespace equss
+
+extern "C" int equss_profile_enable(int max_pairs) {
+    using namespace equss;
+    if (g_pairs) {
+        for (int i = 0; i < g_cap; ++i) { (void)hipEventDestroy(g_pairs[i].a); (void)hipEventDestroy(g_pairs[i].b); }
+        delete[] g_pairs;
+        g_pairs = nullptr;
+    }
+    g_cap = g_used = 0;
+    g_on = false;
+    if (max_pairs <= 0) return EQUSS_OK;
+    g_pairs = new Pair[max_pairs];
+    for (int i = 0; i < max_pairs; ++i) {
+        if (hipEventCreate(&g_pairs[i].a) != hipSuccess || hipEventCreate(&g_pairs[i].b) != hipSuccess)
+            return fail(EQUSS_E_UNSUPPORTED, "profile_enable: cannot create event pair %d", i);
+        g_cap = i + 1;
+    }
+    g_on = true;
+    return EQUSS_OK;
+}
+
+extern "C" int equss_profile_read(double* ms, int64_t* launches, int reset) {
+    using namespace equss;
+    if (!ms || !launches) return fail(EQUSS_E_NULL, "profile_read: null pointer argument");
+    for (int i = 0; i < g_used; ++i) {
+        hipError_t e = hipEventSynchronize(g_pairs[i].b);
+        float t = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&t, g_pairs[i].a, g_pairs[i].b);
+        if (e != hipSuccess) { fail(0, "profile_read: %s", hipGetErrorString(e)); return -(int)e; }
+        ms[g_pairs[i].cls] += (double)t;
+        launches[g_pairs[i].cls] += 1;
+    }
+    if (reset) g_used = 0;
+    return EQUSS_OK;
+}
 
 extern "C" int equss_abi_version(void) { return EQUSS_ABI_VERSION; }
 extern "C" const char* equss_last_error(void) { return equss::error_buffer(); }

@@ -21,6 +21,16 @@ namespace equss {
 char* error_buffer();
 int fail(int code, const char* fmt, ...);
 
+// Event-pair recording around launches (see equss_profile_enable in the public header).
+bool prof_on();
+void prof_begin(int cls, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+    hipStream_t s; bool on;
+    ProfScope(int cls, hipStream_t st) : s(st), on(prof_on()) { if (on) prof_begin(cls, s); }
+    ~ProfScope() { if (on) prof_end(s); }
+};
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

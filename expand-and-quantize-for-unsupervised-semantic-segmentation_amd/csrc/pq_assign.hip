@@ -422,11 +422,14 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
         return equss::fail(EQUSS_E_ALIGN, "pq_assign: zq must be 16-byte aligned with ld_zq a multiple of 4");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     PqWorkspace w = carve(workspace, num_pq, K, d);
-    switch (d) {
-        case 16: rc = launch_prep<16>(codebooks, w, num_pq * K, normalize, s); break;
-        case 32: rc = launch_prep<32>(codebooks, w, num_pq * K, normalize, s); break;
-        case 64: rc = launch_prep<64>(codebooks, w, num_pq * K, normalize, s); break;
-        default: rc = launch_prep<128>(codebooks, w, num_pq * K, normalize, s); break;
+    {
+        equss::ProfScope ps(EQUSS_K_PQ_PREP, s);
+        switch (d) {
+            case 16: rc = launch_prep<16>(codebooks, w, num_pq * K, normalize, s); break;
+            case 32: rc = launch_prep<32>(codebooks, w, num_pq * K, normalize, s); break;
+            case 64: rc = launch_prep<64>(codebooks, w, num_pq * K, normalize, s); break;
+            default: rc = launch_prep<128>(codebooks, w, num_pq * K, normalize, s); break;
+        }
     }
     if (rc) return rc;
     PqArgs a;
@@ -440,11 +443,14 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx > kMaxGridX) gx = kMaxGridX;
     if (gx < 1) gx = 1;
-    switch (d) {
-        case 16: rc = dispatch_nt<16>(a, pl, gx, s); break;
-        case 32: rc = dispatch_nt<32>(a, pl, gx, s); break;
-        case 64: rc = dispatch_nt<64>(a, pl, gx, s); break;
-        default: rc = dispatch_nt<128>(a, pl, gx, s); break;
+    {
+        equss::ProfScope ps(EQUSS_K_PQ_ASSIGN, s);
+        switch (d) {
+            case 16: rc = dispatch_nt<16>(a, pl, gx, s); break;
+            case 32: rc = dispatch_nt<32>(a, pl, gx, s); break;
+            case 64: rc = dispatch_nt<64>(a, pl, gx, s); break;
+            default: rc = dispatch_nt<128>(a, pl, gx, s); break;
+        }
     }
     if (rc) return rc;
     if (loss_sum) {

@@ -249,20 +249,30 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     VitWs w = carve_vit(workspace, C, B, H, W, P);
     const int n = (H / P) * (W / P), N = n + 1, rows = B * N;
-    rc = patch_tokens(img, vit->patch_w, vit->patch_b, vit->cls, pos, w.x, w.patch, B, H, W, P, C, s);
+    {
+        equss::ProfScope ps(EQUSS_K_PATCH, s);
+        rc = patch_tokens(img, vit->patch_w, vit->patch_b, vit->cls, pos, w.x, w.patch, B, H, W, P, C, s);
+    }
     if (rc) return rc;
     const float scale = 0.125f;  // head_dim ** -0.5 with head_dim = 64 (vision_transformer.py:71-72)
     for (int i = 0; i < vit->depth; ++i) {
         const EqussVitBlock& k = vit->blocks[i];
-        if ((rc = layernorm(w.x, C, k.ln1_g, k.ln1_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))) return rc;
-        if ((rc = equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))) return rc;
-        if ((rc = equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))) return rc;
-        if ((rc = equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))) return rc;
-        if ((rc = layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))) return rc;
-        if ((rc = equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))) return rc;
-        if ((rc = equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))) return rc;
+#define EQUSS_STEP(cls, call)                 \
+    {                                         \
+        equss::ProfScope ps(cls, s);          \
+        rc = (call);                          \
+    }                                         \
+    if (rc) return rc;
+        EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln1_g, k.ln1_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        EQUSS_STEP(EQUSS_K_GEMM_QKV, equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))
+        EQUSS_STEP(EQUSS_K_ATTENTION, equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))
+        EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))
+        EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        EQUSS_STEP(EQUSS_K_GEMM_FC1, equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))
+        EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))
     }
-    return layernorm(w.x, C, vit->norm_g, vit->norm_b, feat_bf16, ld_feat, feat_f32, rows, C, N, 1e-6f, s);
+    EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, vit->norm_g, vit->norm_b, feat_bf16, ld_feat, feat_f32, rows, C, N, 1e-6f, s))
+    return EQUSS_OK;
 }
 
 // code = [f | relu(f W2a^T + b2a)] [W1 | W2b]^T + (b1 + b2b)   (model/dino_pqgo.py:104-112,:127-128)
@@ -271,7 +281,8 @@ extern "C" int equss_expand_head(void* fh, const void* w2a, const float* b2a, co
     if (!fh || !w2a || !b2a || !w_cat || !b_cat || !code) return equss::fail(EQUSS_E_NULL, "expand_head: null pointer argument");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     u16* f = reinterpret_cast<u16*>(fh);
-    int rc = equss::gemm_bf16(f, 2 * C, w2a, C, b2a, f + C, 2 * C, rows, C, C, EQUSS_EPI_RELU_BF16, s);
-    if (rc) return rc;
-    return equss::gemm_bf16(f, 2 * C, w_cat, 2 * C, b_cat, code, D, rows, D, 2 * C, EQUSS_EPI_F32, s);
+    int rc;
+    EQUSS_STEP(EQUSS_K_HEAD_GEMM1, equss::gemm_bf16(f, 2 * C, w2a, C, b2a, f + C, 2 * C, rows, C, C, EQUSS_EPI_RELU_BF16, s))
+    EQUSS_STEP(EQUSS_K_HEAD_GEMM2, equss::gemm_bf16(f, 2 * C, w_cat, 2 * C, b_cat, code, D, rows, D, 2 * C, EQUSS_EPI_F32, s))
+    return EQUSS_OK;
 }

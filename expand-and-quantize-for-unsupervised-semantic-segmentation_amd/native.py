@@ -16,7 +16,7 @@ NORM_MODES = {"none": 0, "l2": 1, "z_norm": 2}
 EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3, 4
 
 EXPORTED_SYMBOLS = [
-    "equss_abi_version", "equss_last_error",
+    "equss_abi_version", "equss_last_error", "equss_profile_enable", "equss_profile_read",
     "equss_pq_workspace_bytes", "equss_pq_assign", "equss_pq_prob",
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
@@ -52,6 +52,10 @@ def _declare(lib):
     lib.equss_abi_version.argtypes = []
     lib.equss_last_error.restype = ctypes.c_char_p
     lib.equss_last_error.argtypes = []
+    lib.equss_profile_enable.restype = c_int
+    lib.equss_profile_enable.argtypes = [c_int]
+    lib.equss_profile_read.restype = c_int
+    lib.equss_profile_read.argtypes = [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(c_i64), c_int]
     lib.equss_pq_workspace_bytes.restype = c_sz
     lib.equss_pq_workspace_bytes.argtypes = [c_int] * 4
     lib.equss_pq_assign.restype = c_int
@@ -134,6 +138,24 @@ def _workspace(device, nbytes, tag):
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
+
+
+KERNEL_CLASSES = ["patch", "layernorm", "gemm_qkv", "attention", "gemm_proj", "gemm_fc1", "gemm_fc2",
+                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign"]
+
+
+def profile_enable(max_pairs):
+    """Start (max_pairs > 0) or stop (0) recording a HIP event pair around every kernel-class launch."""
+    _check(load_library().equss_profile_enable(int(max_pairs)), "equss_profile_enable")
+
+
+def profile_read(reset=True):
+    """{class: (total_ms, launches)} of everything recorded since the last reset (synchronises)."""
+    n = len(KERNEL_CLASSES)
+    ms = (ctypes.c_double * n)()
+    cnt = (ctypes.c_int64 * n)()
+    _check(load_library().equss_profile_read(ms, cnt, int(bool(reset))), "equss_profile_read")
+    return {k: (ms[i], cnt[i]) for i, k in enumerate(KERNEL_CLASSES)}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -56,6 +56,34 @@ int equss_abi_version(void);
 const char* equss_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
+ * Per-kernel-class device timing (HIP events recorded on the caller's stream around every launch
+ * the whole-path entry points make).  The reference's only instrumentation is host wall clock
+ * around the forward (train.py:59-98) and two device synchronisations around its loss
+ * (model/dino_pqgo.py:145-150); this replaces both without synchronising inside the path.
+ *   equss_profile_enable(max_pairs): create an event pool and start recording; 0 disables and
+ *     destroys the pool.  While the pool is exhausted launches simply go unrecorded.
+ *   equss_profile_read(ms, launches, reset): synchronises the recorded events and ADDS the elapsed
+ *     milliseconds / launch counts per class into ms[EQUSS_K_COUNT] / launches[EQUSS_K_COUNT]
+ *     (HOST arrays); reset != 0 recycles the pool afterwards.
+ * ------------------------------------------------------------------------------------------- */
+enum {
+    EQUSS_K_PATCH = 0,     /* patch gather + patch GEMM + token assembly */
+    EQUSS_K_LAYERNORM = 1,
+    EQUSS_K_GEMM_QKV = 2,
+    EQUSS_K_ATTENTION = 3,
+    EQUSS_K_GEMM_PROJ = 4,
+    EQUSS_K_GEMM_FC1 = 5,
+    EQUSS_K_GEMM_FC2 = 6,
+    EQUSS_K_HEAD_GEMM1 = 7,
+    EQUSS_K_HEAD_GEMM2 = 8,
+    EQUSS_K_PQ_PREP = 9,
+    EQUSS_K_PQ_ASSIGN = 10,
+    EQUSS_K_COUNT = 11
+};
+int equss_profile_enable(int max_pairs);
+int equss_profile_read(double* ms, int64_t* launches, int reset);
+
+/* ---------------------------------------------------------------------------------------------
  * Product-quantisation assign.
  * Replaces ProductQuantizerWrapper.forward + Codebook.forward (model/dino_pqgo.py:745-776,
  * :579-705) and the same core in model/quantizer.py:105-189, :383-542, :587-611:
