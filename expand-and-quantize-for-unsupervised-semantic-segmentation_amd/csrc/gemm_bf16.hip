@@ -21,9 +21,9 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kStageBytes = (BM + BN) * BK * 2;  // 32 KiB
+constexpr int BM = 128, BN = 128;
 constexpr int kThreads = 256;
+int g_bk = 64;  // K step; 32 halves the LDS stage so four workgroups fit a CU
 
 struct GemmArgs {
     const u16* A; int64_t lda;
@@ -33,8 +33,22 @@ struct GemmArgs {
     int M, N, K, ntn;  // ntn = N / BN
 };
 
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 rounding of the result):
+// one v_rcp, one v_exp and five fma instead of the ~30-instruction branchy library erff.
+__device__ __forceinline__ float erf_as(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p, e, 1.0f);
+    return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -43,8 +57,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
         (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI>
+template <int EPI, int BK>
 __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g) {
+    constexpr int kStageBytes = (BM + BN) * BK * 2;
+    constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
+    constexpr int RPP = 1024 / (BK * 2);        // tile rows per 1-KiB LDS-DMA piece
+    constexpr int PIECES = BM / RPP / 4;        // pieces per operand per wave
+    constexpr int KS = BK / 32;                 // MFMA k sub-steps per K step
+    // chunk swizzle: rows sharing a 256-byte bank row get distinct XOR masks
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -60,14 +81,14 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
     const int n0 = (logical % g.ntn) * BN;
 
     // ---- staging plan: 4 LDS-DMA pieces per operand per wave, 8 rows x 128 B each -------------
-    const u16* a_src[4];
-    const u16* w_src[4];
-    int lds_row[4];
+    const u16* a_src[PIECES];
+    const u16* w_src[PIECES];
+    int lds_row[PIECES];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rowgrp = (i * 4 + wave) * 8;
-        const int row = rowgrp + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+    for (int i = 0; i < PIECES; ++i) {
+        const int rowgrp = (i * 4 + wave) * RPP;
+        const int row = rowgrp + lane / CPR;
+        const int chunk = (lane % CPR) ^ swz(row);
         int am = m0 + row;
         if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; their outputs are masked
         a_src[i] = g.A + (size_t)am * g.lda + chunk * 8;
@@ -77,7 +98,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
     auto stage = [&](int buf, int kt) {
         char* base = smem + buf * kStageBytes;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < PIECES; ++i) {
             glds16(a_src[i] + (size_t)kt * BK, base + lds_row[i]);
             glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + lds_row[i]);
         }
@@ -85,10 +106,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
 
     // ---- fragment read offsets ----------------------------------------------------------------
     const int fr = lane & 15, fq = lane >> 4;
-    const int sw = fr >> 1;  // (row >> 1) & 7 for row = 16 * x + fr
-    int a_off[2], w_off[2];  // byte offset of this lane's chunk for k sub-step 0 / 1 within a 16-row group
+    const int sw = swz(fr);  // swizzle mask of row 16 * x + fr
+    int a_off[KS], w_off[KS];  // byte offset of this lane's chunk per k sub-step within a 16-row group
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
         const int off = fr * (BK * 2) + (((4 * ks + fq) ^ sw) * 16);
         a_off[ks] = (wave_m * 64) * (BK * 2) + off;
         w_off[ks] = BM * BK * 2 + (wave_n * 64) * (BK * 2) + off;
@@ -108,7 +129,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
         if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
         const char* base = smem + (kt & 1) * kStageBytes;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
             bf16x8 af[4], wf[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -161,7 +182,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
 template <int EPI>
 int launch(const GemmArgs& g, hipStream_t s) {
     const int grid = ((g.M + BM - 1) / BM) * g.ntn;
-    hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(grid), dim3(kThreads), 2 * kStageBytes, s, g);
+    if (g_bk == 32)
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 32>), dim3(grid), dim3(kThreads), 2 * (BM + BN) * 32 * 2, s, g);
+    else
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(grid), dim3(kThreads), 2 * (BM + BN) * 64 * 2, s, g);
     return equss::check_launch("gemm_bf16_kernel");
 }
 
@@ -173,8 +197,8 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
               int M, int N, int K, int epilogue, hipStream_t s) {
     if (!A || !W || !out) return fail(EQUSS_E_NULL, "gemm_bf16: null pointer argument");
     if (M <= 0 || N <= 0 || K <= 0) return fail(EQUSS_E_SHAPE, "gemm_bf16: M=%d N=%d K=%d must be positive", M, N, K);
-    if (N % BN != 0 || K % BK != 0)
-        return fail(EQUSS_E_SHAPE, "gemm_bf16: N=%d must be a multiple of %d and K=%d of %d", N, BN, K, BK);
+    if (N % BN != 0 || K % 64 != 0)
+        return fail(EQUSS_E_SHAPE, "gemm_bf16: N=%d must be a multiple of %d and K=%d of 64", N, BN, K);
     if (lda < K || ldw < K || ldo < N || (lda % 8) || (ldw % 8) || (ldo % 4) || ((uintptr_t)A % 16) ||
         ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (bias && ((uintptr_t)bias % 16)))
         return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
@@ -193,6 +217,8 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
 }
 
 }  // namespace equss
+
+extern "C" void equss_dev_gemm_bk(int bk) { g_bk = bk == 32 ? 32 : 64; }  // tuning knob, not part of the ABI
 
 extern "C" int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
