@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--res", type=int, default=320)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--gemm-bk", type=int, default=0, help="developer knob: GEMM K step (32 or 64); 0 = library default")
+    ap.add_argument("--gemm-variant", type=int, default=-1, help="developer knob: GEMM kernel variant; -1 = library default")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,8 +91,8 @@ def main():
         dist.init_process_group(backend="nccl")  # RCCL over xGMI on ROCm
 
     pkg = importlib.import_module(PKG)
-    if args.gemm_bk:
-        pkg.native.load_library().equss_dev_gemm_bk(args.gemm_bk)
+    if args.gemm_variant >= 0:
+        pkg.native.load_library().equss_dev_gemm_variant(args.gemm_variant)
     cfg = pkg.configs.S_CFG
     state = pkg.synth.synth_pqgo_state(cfg, seed=1234)
     model = pkg.build_model(cfg)

@@ -1,0 +1,347 @@
+// Large-tile, persistent, deep-ring variant of C = A * W^T + bias (bf16 MFMA, fp32 accumulate,
+// fused store-only epilogue).
+//
+// Why a second GEMM kernel.  PMC counters on the 128 x 128 two-stage kernel show its waves parked
+// 57-59 % of the time at the vmcnt/barrier that ends every K step while the matrix pipe is busy
+// 22 % of the time: a CU with one 32-64 KiB stage in flight sustains only ~26 GB/s of L2 -> LDS
+// traffic (bytes in flight / latency), far below what the MFMAs can eat.  Two levers, both here:
+//   * more flop per byte: tiles of 128 x 384 (N a multiple of 384: qkv, proj, fc1, fc2, patch
+//     embed, head GEMM 1) or 256 x 256 (N a multiple of 256: head GEMM 2), 96-128 flop/B instead
+//     of 64;
+//   * more bytes in flight: an S-stage LDS ring filled by global_load_lds_dwordx4 S-1 K steps
+//     ahead and retired with COUNTED s_waitcnt vmcnt(N) + a raw s_barrier, so loads stay in flight
+//     across barriers and across tiles (the ring never drains: workgroups are persistent and the
+//     issue cursor runs into the next tile while the compute cursor finishes the current one).
+// One workgroup = 8 waves (two per SIMD) = one tile; one workgroup per CU; tiles are walked in an
+// XCD-contiguous order so neighbours in time share operand panels in that XCD's L2.
+// The epilogue only stores (the residual add lives in the LayerNorm that follows), which keeps the
+// in-order vmcnt queue free of epilogue loads that would otherwise drain the ring.
+// Fragment layout, chunk swizzle and the C^T trick are those of gemm_bf16.hip.
+#include "equss_common.h"
+
+namespace {
+
+constexpr int kThreads = 512;
+
+struct Gemm8Args {
+    const u16* A; int64_t lda;
+    const u16* W; int64_t ldw;
+    const float* bias;
+    void* out; int64_t ldo;
+    int M, N, K, ntn, nostore;
+};
+
+__device__ __forceinline__ float erf_as(float x) {  // Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p *= t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    return copysignf(fmaf(-p, e, 1.0f), x);
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const void __attribute__((address_space(1)))*)gsrc,
+        (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+// Wait until at most `stages * PW (+ NST)` of this wave's vector-memory operations are outstanding.
+// Operations retire in issue order, so "the loads of ring stage j have landed" is exactly "no more
+// operations are outstanding than were issued after them": `stages` younger ring stages of PW loads
+// each, plus the NST stores of an epilogue when that epilogue was issued after stage j's loads.
+template <int PW, int NST>
+__device__ __forceinline__ void wait_younger(int stages, bool stores_younger) {
+#define EQUSS_W(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+    if (stores_younger) {
+        switch (stages) {
+            case 0: EQUSS_W(NST); break;
+            case 1: EQUSS_W(PW + NST); break;
+            case 2: EQUSS_W(2 * PW + NST); break;
+            case 3: EQUSS_W(3 * PW + NST); break;
+            default: EQUSS_W(4 * PW + NST); break;
+        }
+    } else {
+        switch (stages) {
+            case 0: EQUSS_W(0); break;
+            case 1: EQUSS_W(PW); break;
+            case 2: EQUSS_W(2 * PW); break;
+            case 3: EQUSS_W(3 * PW); break;
+            default: EQUSS_W(4 * PW); break;
+        }
+    }
+#undef EQUSS_W
+}
+
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
+__global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
+    static_assert(WM * WN == 8, "eight waves");
+    static_assert(S >= 2 && S <= 6, "ring depth");
+    constexpr int TM = BM / WM, TN = BN / WN;      // per-wave output tile
+    constexpr int MT = TM / 16, NT = TN / 16;      // 16 x 16 MFMA tiles per wave
+    constexpr int ROWB = BK * 2;                   // bytes per tile row
+    constexpr int CPR = BK / 8;                    // 16-byte chunks per row
+    constexpr int RPP = 1024 / ROWB;               // rows per 1-KiB LDS-DMA piece
+    constexpr int KS = BK / 32;                    // MFMA k sub-steps per K step
+    constexpr int kStageBytes = (BM + BN) * ROWB;
+    constexpr int A_PIECES = BM / RPP;
+    constexpr int PW = (BM + BN) / RPP / 8;        // pieces per wave per stage
+    // bf16 epilogue geometry (see the epilogue): rows per pass and 16-byte stores per lane per tile
+    constexpr int ROWSTRIDE = TN * 2 + 16;
+    constexpr int RP = (kStageBytes / 8 >= 32 * ROWSTRIDE && TM >= 32) ? 32 : 16;
+    constexpr int OCH = TN * 2 / 16;
+    constexpr int PER_LANE = RP * OCH / 64;
+    constexpr int NST = EPI == EQUSS_EPI_F32 ? 0 : PER_LANE * (TM / RP);
+    static_assert((S - 1) * PW + NST <= 63, "vmcnt range");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+
+    const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int x_start = xcd * q + (xcd < r ? xcd : r);
+    const int x_len = q + (xcd < r ? 1 : 0);
+    const int nslots = (gridDim.x + 7 - xcd) >> 3;
+    if (slot >= x_len) return;
+    const int my_tiles = (x_len - slot + nslots - 1) / nslots;
+    const int nk = g.K / BK;
+    const int total = my_tiles * nk;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    int c_off[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) c_off[ks] = ((4 * ks + fq) ^ swz(fr)) * 16;
+    const int a_base = (wm * TM + fr) * ROWB;
+    const int w_base = BM * ROWB + (wn * TN + fr) * ROWB;
+
+    // ---- issue cursor: which (tile, K step) is staged next, and into which ring slot -------------
+    const int st_row = lane / CPR, st_phys = lane % CPR;
+    const u16* src[PW];
+    int i_tile = slot, i_kt = 0, i_buf = 0, issued = 0;
+    auto set_src = [&](int logical) {
+        const int m0 = (logical / g.ntn) * BM;
+        const int n0 = (logical % g.ntn) * BN;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) {
+            const int p = i * 8 + wave;  // pieces [0, A_PIECES) are activation rows, the rest weight rows
+            const int row = (p < A_PIECES ? p : p - A_PIECES) * RPP + st_row;
+            const int chunk = (st_phys ^ swz(row)) * 8;
+            if (p < A_PIECES) {
+                int am = m0 + row;
+                if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; outputs are masked
+                src[i] = g.A + (size_t)am * g.lda + chunk;
+            } else {
+                src[i] = g.W + (size_t)(n0 + row) * g.ldw + chunk;
+            }
+        }
+    };
+    auto issue_one = [&]() {
+        if (issued >= total) return;
+        char* base = smem + i_buf * kStageBytes;
+#pragma unroll
+        for (int i = 0; i < PW; ++i) glds16(src[i] + (size_t)i_kt * BK, base + (i * 8 + wave) * 1024);
+        ++issued;
+        i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
+        if (++i_kt == nk) {
+            i_kt = 0;
+            i_tile += nslots;
+            if (issued < total) set_src(x_start + i_tile);
+        }
+    };
+    // bias -> LDS once, before the ring starts: an ordinary global load inside the loop would make the
+    // compiler wait for it, and with it (in-order retirement) for every prefetch issued before it.
+    float* bias_s = reinterpret_cast<float*>(smem + S * kStageBytes);
+    for (int i = tid; i < g.N; i += kThreads) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+    __syncthreads();
+    set_src(x_start + i_tile);
+#pragma unroll
+    for (int d = 0; d < S - 1; ++d) issue_one();
+
+    // ---- compute cursor ----------------------------------------------------------------------------
+    int c_tile = slot, c_buf = 0, step = 0;
+    int epi_mark = 0;  // ring stages [0, epi_mark) were issued before the latest exact-count epilogue
+    for (int t = 0; t < my_tiles; ++t, c_tile += nslots) {
+        const int logical = x_start + c_tile;
+        const int m0 = (logical / g.ntn) * BM;
+        const int n0 = (logical % g.ntn) * BN;
+        f32x4 acc[NT][MT];  // element j <-> output column n + j
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kt = 0; kt < nk; ++kt, ++step) {
+            // this wave's pieces of stage `step` have landed once at most (issued - step - 1) younger
+            // stages are outstanding (operations retire in order; epilogue stores in the queue only make
+            // the wait stricter); the barrier then covers the other waves' pieces, and tells everyone
+            // that ring slot (step - 1) % S is no longer being read.
+            wait_younger<PW, NST>(issued - step - 1, step < epi_mark);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            issue_one();
+            const char* base = smem + c_buf * kStageBytes;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 af[MT], wf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(base + a_base + i * 16 * ROWB + c_off[ks]);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    wf[i] = *reinterpret_cast<const bf16x8*>(base + w_base + i * 16 * ROWB + c_off[ks]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+            }
+            asm volatile("" ::: "memory");
+            c_buf = c_buf + 1 == S ? 0 : c_buf + 1;
+        }
+        // ---- epilogue (stores only) ---------------------------------------------------------------------
+        if constexpr (EPI == EQUSS_EPI_F32) {
+            // lane owns out[m][n .. n+3] as one 16-byte store
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = n0 + wn * TN + nt * 16 + fq * 4;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + n);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = m0 + wm * TM + mt * 16 + fr;
+                    if (m >= g.M) continue;
+                    f32x4 v = acc[nt][mt];
+                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n) = v;
+                }
+            }
+        } else {
+            // bf16 output: a lane's fragment is only 8 bytes wide, and 32-byte row segments make the write
+            // path crawl (measured ~9 GB/s per CU).  Re-shape each wave's sub-tile through the ring slot
+            // that was just consumed (free until the next K step is staged into it): 8-byte fragment
+            // writes in, 16-byte row-contiguous reads out, then 16-byte stores covering whole rows.
+            // ROWSTRIDE = padded LDS row, RP = rows per pass, OCH = 16-byte chunks per output row.
+            static_assert(RP * OCH % 64 == 0, "epilogue chunking");
+            // A full tile issues exactly NST stores per wave, which lets the waits that follow leave them
+            // in flight; the ragged last row-tile masks stores, so it falls back to the stricter wait.
+            const bool full = m0 + BM <= g.M && !g.nostore;
+            epi_mark = full ? issued : 0;
+            const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
+            char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / 8);
+            __builtin_amdgcn_s_barrier();  // every wave is done reading that slot
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int pass = 0; pass < TM / RP; ++pass) {
+#pragma unroll
+                for (int ml = 0; ml < RP / 16; ++ml) {
+                    const int mt = pass * (RP / 16) + ml;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + n0 + wn * TN + nt * 16 + fq * 4);
+                        f32x4 v = acc[nt][mt];
+                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                        if constexpr (EPI == EQUSS_EPI_GELU_BF16) {
+                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                        }
+                        if constexpr (EPI == EQUSS_EPI_RELU_BF16) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                        uint2 pk;
+                        pk.x = equss::pack_bf16(v.x, v.y);
+                        pk.y = equss::pack_bf16(v.z, v.w);
+                        *reinterpret_cast<uint2*>(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
+                    }
+                }
+                asm volatile("" ::: "memory");  // same-wave LDS accesses execute in order
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) {
+                    const int idx = j * 64 + lane;
+                    const int row = idx / OCH, ch = idx % OCH;
+                    const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
+                    const int m = m0 + wm * TM + pass * RP + row;
+                    if (g.nostore) { asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); continue; }
+                    if (full || m < g.M)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n0 + wn * TN + ch * 8) = d;
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+    }
+}
+
+int g_stages = 2;
+int g_nostore = 0;
+
+template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
+int launch_inst(const Gemm8Args& g, hipStream_t s) {
+    const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
+    const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
+    constexpr int ring = S * (BM + BN) * BK * 2;
+    static_assert(ring + 16384 <= 163840, "LDS budget");
+    if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
+    const int lds = ring + g.N * 4;
+    auto kern = gemm8_kernel<EPI, BM, BN, WM, WN, BK, S>;
+    static bool attr_done = false;  // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
+            hipSuccess)
+            return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: cannot reserve %d bytes of LDS", lds);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, g);
+    return equss::check_launch("gemm8_kernel");
+}
+
+template <int EPI, int BM, int BN, int WM, int WN>
+int launch_shape(const Gemm8Args& g, hipStream_t s) {
+    switch (g_stages) {
+        case 2: return launch_inst<EPI, BM, BN, WM, WN, 64, 2>(g, s);
+        case 3: return launch_inst<EPI, BM, BN, WM, WN, 32, 3>(g, s);
+        default: return launch_inst<EPI, BM, BN, WM, WN, 32, 4>(g, s);
+    }
+}
+
+template <int EPI>
+int launch(Gemm8Args& g, hipStream_t s) {
+    if (g.N % 384 == 0) {
+        g.ntn = g.N / 384;
+        return launch_shape<EPI, 128, 384, 2, 4>(g, s);
+    }
+    g.ntn = g.N / 256;
+    return launch_shape<EPI, 256, 256, 2, 4>(g, s);
+}
+
+}  // namespace
+
+namespace equss {
+
+bool gemm8_supports(int N, int K, int epilogue) {
+    return (N % 384 == 0 || N % 256 == 0) && K % 64 == 0 && epilogue != EQUSS_EPI_RESID_F32;
+}
+
+int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+               int M, int N, int K, int epilogue, hipStream_t s) {
+    Gemm8Args g;
+    g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
+    g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
+    g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.ntn = 0; g.nostore = g_nostore;
+    switch (epilogue) {
+        case EQUSS_EPI_BF16: return launch<EQUSS_EPI_BF16>(g, s);
+        case EQUSS_EPI_GELU_BF16: return launch<EQUSS_EPI_GELU_BF16>(g, s);
+        case EQUSS_EPI_RELU_BF16: return launch<EQUSS_EPI_RELU_BF16>(g, s);
+        case EQUSS_EPI_F32: return launch<EQUSS_EPI_F32>(g, s);
+        default: return fail(EQUSS_E_UNSUPPORTED, "gemm8: unsupported epilogue %d", epilogue);
+    }
+}
+
+}  // namespace equss
+
+extern "C" void equss_dev_gemm_stages(int s) { g_stages = s & 15; g_nostore = (s >> 4) & 1; }  // tuning knob, not part of the ABI

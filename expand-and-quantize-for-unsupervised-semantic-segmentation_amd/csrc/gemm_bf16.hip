@@ -23,7 +23,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128;
 constexpr int kThreads = 256;
-int g_bk = 64;  // K step; 32 halves the LDS stage so four workgroups fit a CU
 
 struct GemmArgs {
     const u16* A; int64_t lda;
@@ -57,94 +56,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
         (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-template <int EPI, int BK>
-__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g) {
-    constexpr int kStageBytes = (BM + BN) * BK * 2;
-    constexpr int CPR = BK / 8;                 // 16-byte chunks per tile row
-    constexpr int RPP = 1024 / (BK * 2);        // tile rows per 1-KiB LDS-DMA piece
-    constexpr int PIECES = BM / RPP / 4;        // pieces per operand per wave
-    constexpr int KS = BK / 32;                 // MFMA k sub-steps per K step
-    // chunk swizzle: rows sharing a 256-byte bank row get distinct XOR masks
-    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wave_m = wave >> 1, wave_n = wave & 1;
+int g_variant = 3;  // 3: large-tile ring kernel where it applies, persistent 128x128 kernel otherwise
 
-    // XCD-aware bijective remap: ids that share (id % 8) share an XCD; give each XCD a contiguous
-    // run of logical tiles so neighbours in time share the activation panel in that XCD's L2.
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, slot = bid >> 3;
-    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
-    const int m0 = (logical / g.ntn) * BM;
-    const int n0 = (logical % g.ntn) * BN;
-
-    // ---- staging plan: 4 LDS-DMA pieces per operand per wave, 8 rows x 128 B each -------------
-    const u16* a_src[PIECES];
-    const u16* w_src[PIECES];
-    int lds_row[PIECES];
-#pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int rowgrp = (i * 4 + wave) * RPP;
-        const int row = rowgrp + lane / CPR;
-        const int chunk = (lane % CPR) ^ swz(row);
-        int am = m0 + row;
-        if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; their outputs are masked
-        a_src[i] = g.A + (size_t)am * g.lda + chunk * 8;
-        w_src[i] = g.W + (size_t)(n0 + row) * g.ldw + chunk * 8;
-        lds_row[i] = rowgrp * (BK * 2);
-    }
-    auto stage = [&](int buf, int kt) {
-        char* base = smem + buf * kStageBytes;
-#pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            glds16(a_src[i] + (size_t)kt * BK, base + lds_row[i]);
-            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + lds_row[i]);
-        }
-    };
-
-    // ---- fragment read offsets ----------------------------------------------------------------
-    const int fr = lane & 15, fq = lane >> 4;
-    const int sw = swz(fr);  // swizzle mask of row 16 * x + fr
-    int a_off[KS], w_off[KS];  // byte offset of this lane's chunk per k sub-step within a 16-row group
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int off = fr * (BK * 2) + (((4 * ks + fq) ^ sw) * 16);
-        a_off[ks] = (wave_m * 64) * (BK * 2) + off;
-        w_off[ks] = BM * BK * 2 + (wave_n * 64) * (BK * 2) + off;
-    }
-
-    f32x4 acc[4][4];  // [nt][mt], element j <-> output column n + j
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nk = g.K / BK;
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // tile kt has landed for every wave; buffer (kt+1)&1 is no longer read
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* base = smem + (kt & 1) * kStageBytes;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 af[4], wf[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                af[t] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + t * 16 * (BK * 2));
-                wf[t] = *reinterpret_cast<const bf16x8*>(base + w_off[ks] + t * 16 * (BK * 2));
-            }
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
-        }
-    }
-
-    // ---- epilogue: lane owns out[m][n .. n+3] -------------------------------------------------
+template <int EPI>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int m0, int n0, int wave_m, int wave_n,
+                                         int fr, int fq) {
+    // lane owns out[m][n .. n+3]
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
         const int n = n0 + wave_n * 64 + nt * 16 + fq * 4;
@@ -179,19 +96,170 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
     }
 }
 
+// VAR 0: one tile per workgroup.  VAR 1: same, fragments of a whole K step preloaded ahead of the
+// MFMA cluster.  VAR 2: VAR 1 + persistent walk over tiles with the next tile's first stage
+// prefetched under the epilogue.
+template <int EPI, int VAR>
+__global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g) {
+    constexpr int BK = 64;
+    constexpr int kStageBytes = (BM + BN) * BK * 2;
+    constexpr int PIECES = 4;                   // 1-KiB LDS-DMA pieces (8 rows x 128 B) per operand per wave
+    auto swz = [](int row) { return (row >> 1) & 7; };  // chunk swizzle of a 128-byte row
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wave >> 1, wave_n = wave & 1;
+
+    // XCD-aware tile order: workgroup ids that share (id % 8) share an XCD; each XCD owns a
+    // contiguous run of logical tiles (n fastest), so tiles that run together share the activation
+    // row-panel in that XCD's L2.
+    const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q = ntiles >> 3, r = ntiles & 7;
+    const int x_start = xcd * q + (xcd < r ? xcd : r);
+    const int x_len = q + (xcd < r ? 1 : 0);
+    const int nslots = (gridDim.x + 7 - xcd) >> 3;  // workgroups resident on this XCD group
+    int it = slot;
+    if (it >= x_len) return;
+
+    const int fr = lane & 15, fq = lane >> 4;
+    const int sw = swz(fr);
+    int a_off[2], w_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int off = fr * (BK * 2) + (((4 * ks + fq) ^ sw) * 16);
+        a_off[ks] = (wave_m * 64) * (BK * 2) + off;
+        w_off[ks] = BM * BK * 2 + (wave_n * 64) * (BK * 2) + off;
+    }
+    const int st_row = lane >> 3;                                // row inside an 8-row piece
+    int st_chunk[PIECES], lds_row[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        const int row = (i * 4 + wave) * 8 + st_row;
+        st_chunk[i] = ((lane & 7) ^ swz(row)) * 8;
+        lds_row[i] = (i * 4 + wave) * 8 * (BK * 2);
+    }
+
+    const u16* a_src[PIECES];
+    const u16* w_src[PIECES];
+    auto set_tile = [&](int logical, int& m0, int& n0) {
+        m0 = (logical / g.ntn) * BM;
+        n0 = (logical % g.ntn) * BN;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int row = (i * 4 + wave) * 8 + st_row;
+            int am = m0 + row;
+            if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; their outputs are masked
+            a_src[i] = g.A + (size_t)am * g.lda + st_chunk[i];
+            w_src[i] = g.W + (size_t)(n0 + row) * g.ldw + st_chunk[i];
+        }
+    };
+    auto stage = [&](int buf, int kt) {
+        char* base = smem + buf * kStageBytes;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            glds16(a_src[i] + (size_t)kt * BK, base + lds_row[i]);
+            glds16(w_src[i] + (size_t)kt * BK, base + BM * BK * 2 + lds_row[i]);
+        }
+    };
+
+    const int nk = g.K / BK;
+    int m0, n0;
+    set_tile(x_start + it, m0, n0);
+    stage(0, 0);
+    int buf = 0;
+    while (true) {
+        f32x4 acc[4][4];  // [nt][mt], element j <-> output column n + j
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int cm0 = m0, cn0 = n0;
+        int nxt = it + nslots;
+        if (VAR < 2 || nxt >= x_len) nxt = -1;
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();  // this K step has landed for every wave; the other buffer is no longer read
+            if (kt + 1 < nk) {
+                stage(buf ^ 1, kt + 1);
+            } else if (nxt >= 0) {
+                set_tile(x_start + nxt, m0, n0);
+                stage(buf ^ 1, 0);
+            }
+            const char* base = smem + buf * kStageBytes;
+            if constexpr (VAR == 0) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 af[4], wf[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        af[t] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + t * 16 * (BK * 2));
+                        wf[t] = *reinterpret_cast<const bf16x8*>(base + w_off[ks] + t * 16 * (BK * 2));
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                }
+            } else {
+                bf16x8 af[2][4], wf[2][4];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        af[ks][t] = *reinterpret_cast<const bf16x8*>(base + a_off[ks] + t * 16 * (BK * 2));
+                        wf[ks][t] = *reinterpret_cast<const bf16x8*>(base + w_off[ks] + t * 16 * (BK * 2));
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nt], af[ks][mt], acc[nt][mt], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf ^= 1;
+        }
+        epilogue<EPI>(g, acc, cm0, cn0, wave_m, wave_n, fr, fq);
+        if (nxt < 0) {
+            if (VAR < 2) break;
+            it += nslots;
+            if (it >= x_len) break;
+            // (only reached when the prefetch was skipped, which VAR 2 never does)
+            break;
+        }
+        it = nxt;
+    }
+}
+
 template <int EPI>
 int launch(const GemmArgs& g, hipStream_t s) {
-    const int grid = ((g.M + BM - 1) / BM) * g.ntn;
-    if (g_bk == 32)
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 32>), dim3(grid), dim3(kThreads), 2 * (BM + BN) * 32 * 2, s, g);
-    else
-        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 64>), dim3(grid), dim3(kThreads), 2 * (BM + BN) * 64 * 2, s, g);
+    const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
+    const size_t lds = 2 * (BM + BN) * 64 * 2;
+    if (g_variant >= 2) {
+        const int grid = ntiles < 512 ? ntiles : 512;  // two resident workgroups per CU
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 2>), dim3(grid), dim3(kThreads), lds, s, g);
+    } else if (g_variant == 1) {
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 1>), dim3(ntiles), dim3(kThreads), lds, s, g);
+    } else {
+        hipLaunchKernelGGL((gemm_bf16_kernel<EPI, 0>), dim3(ntiles), dim3(kThreads), lds, s, g);
+    }
     return equss::check_launch("gemm_bf16_kernel");
 }
 
 }  // namespace
 
 namespace equss {
+
+bool gemm8_supports(int N, int K, int epilogue);
+int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
+               int M, int N, int K, int epilogue, hipStream_t s);
 
 int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
               int M, int N, int K, int epilogue, hipStream_t s) {
@@ -202,6 +270,8 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
     if (lda < K || ldw < K || ldo < N || (lda % 8) || (ldw % 8) || (ldo % 4) || ((uintptr_t)A % 16) ||
         ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (bias && ((uintptr_t)bias % 16)))
         return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
+    if (g_variant == 3 && gemm8_supports(N, K, epilogue))
+        return gemm8_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
     GemmArgs g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
@@ -218,7 +288,7 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
 
 }  // namespace equss
 
-extern "C" void equss_dev_gemm_bk(int bk) { g_bk = bk == 32 ? 32 : 64; }  // tuning knob, not part of the ABI
+extern "C" void equss_dev_gemm_variant(int v) { g_variant = v; }  // tuning knob, not part of the ABI
 
 extern "C" int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream) {
