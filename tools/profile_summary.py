@@ -1,0 +1,68 @@
+"""Condense rocprofv3 output (kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE passes of the
+same bench.py command) into the small files kept under profiles/.
+usage: python tools/profile_summary.py <gpurun_out/prof_dir> <tag>"""
+import collections, csv, glob, json, os, sys
+
+src, tag = sys.argv[1], sys.argv[2]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = os.path.join(root, "profiles")
+os.makedirs(out, exist_ok=True)
+
+CLASS = [("attention_kernel", "attention"), ("pq_assign_kernel", "pq_assign"), ("pq_prep_codebook", "pq_prep"),
+         ("layernorm_kernel", "layernorm"), ("add_layernorm_kernel", "layernorm"),
+         ("gemm8_kernel<1,", "gemm_fc1"), ("gemm8_kernel<0,", "gemm_bf16out"), ("gemm8_kernel<2,", "head_gemm1"),
+         ("gemm8_kernel<3, 256", "head_gemm2"), ("gemm8_kernel<3, 128", "patch_gemm"),
+         ("gemm_bf16_kernel<4", "gemm_resid(proj,fc2)"), ("gemm_bf16_kernel", "gemm_128"),
+         ("patch_gather", "patch_gather"), ("assemble_tokens", "assemble_tokens"), ("pq_loss_reduce", "pq_loss_reduce")]
+
+
+def classify(name):
+    for key, cls in CLASS:
+        if key in name:
+            return cls
+    return None
+
+
+stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["kernel", "class", "calls", "total_ms", "avg_us", "percent"])
+    for r in rows:
+        cls = classify(r["Name"])
+        if cls is None and float(r["Percentage"]) < 0.05:
+            continue
+        w.writerow([r["Name"][:110], cls or "torch/runtime", r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 3),
+                    round(float(r["AverageNs"]) / 1e3, 2), r["Percentage"]])
+
+traffic = collections.defaultdict(lambda: {"fetch_raw_kb": 0.0, "write_raw_kb": 0.0, "launches_f": 0, "launches_w": 0})
+for counter, sub, fld, cnt in (("FETCH_SIZE", "fetch", "fetch_raw_kb", "launches_f"), ("WRITE_SIZE", "write", "write_raw_kb", "launches_w")):
+    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != counter:
+                continue
+            cls = classify(r["Kernel_Name"])
+            if cls is None:
+                continue
+            traffic[cls][fld] += float(r["Counter_Value"])
+            traffic[cls][cnt] += 1
+summary = {}
+for cls, t in traffic.items():
+    if not t["launches_f"] or not t["launches_w"]:
+        continue
+    # rocprofv3 reports KB; on gfx950 FETCH_SIZE counts 64 B per 128-B request of a wide coalesced
+    # stream, i.e. half the bytes read, so it is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.
+    fetch = 2.0 * t["fetch_raw_kb"] / t["launches_f"] * 1024
+    write = t["write_raw_kb"] / t["launches_w"] * 1024
+    summary[cls] = {"hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
+                    "hbm_bytes_per_launch": round(fetch + write), "launches_sampled": t["launches_f"]}
+with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as f:
+    json.dump({"note": "FETCH_SIZE and WRITE_SIZE from two separate rocprofv3 --pmc passes of bench.py; "
+                       "FETCH_SIZE doubled (gfx950 counts half of a wide coalesced read); bytes per launch",
+               "classes": summary}, f, indent=1, sort_keys=True)
+flat = {"attention": summary.get("attention", {}).get("hbm_bytes_per_launch"),
+        "pq_assign": summary.get("pq_assign", {}).get("hbm_bytes_per_launch"),
+        "gemm_fc1": summary.get("gemm_fc1", {}).get("hbm_bytes_per_launch")}
+with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
+    json.dump(flat, f, indent=1, sort_keys=True)
+print(json.dumps(summary, indent=1))
