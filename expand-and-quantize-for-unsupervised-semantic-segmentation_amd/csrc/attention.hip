@@ -4,8 +4,8 @@
 // attention matrix that forward also returns is discarded by its only caller on this path
 // (model/dino/dino_featurizer.py:76-80), so it is never written.
 //
-// One workgroup = 4 waves = 128 queries of one (image, head); each wave owns 32 queries and walks
-// the keys in tiles of 64.
+// One workgroup = 8 waves = 256 queries of one (image, head); each wave owns 32 queries and walks
+// the keys in tiles of 64 (a K/V tile is staged once per 256 queries).
 //  * K and V tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (two stages; the next tile is in
 //    flight while the current one is on the matrix pipe).  K is chunk-swizzled for conflict-free
 //    ds_read_b128; V is swizzled for ds_read_b64_tr_b16, the transposing LDS read that turns
@@ -18,12 +18,14 @@
 //  * Workgroup ids are remapped so the query blocks of one (image, head) run on one XCD and share
 //    its K/V in that XCD's L2.
 #include "equss_common.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int HD = 64;          // head dim
 constexpr int QW = 32;          // queries per wave
-constexpr int QB = 128;         // queries per workgroup
+constexpr int QB = 256;         // queries per workgroup (8 waves)
+constexpr int kAttnThreads = QB / QW * 64;
 constexpr int KV = 64;          // keys per tile
 constexpr int kTile = KV * HD * 2;      // 8 KiB per K or V tile
 constexpr int kStage = 2 * kTile;       // K + V
@@ -45,7 +47,8 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 
-__global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
+template <int DIAG>
+__global__ __launch_bounds__(kAttnThreads, 4) void attention_kernel(const AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,32 +67,31 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     // ---- Q fragments (B operand): lane (query lr, half lh) holds q[16 s + 8 lh + 0..7] -----------
     int qrow = qb * QB + wave * QW + lr;
     const bool q_valid = qrow < a.N;
+    const bool wave_active = qb * QB + wave * QW < a.N;  // waves past the last query only help staging
     if (!q_valid) qrow = a.N - 1;
     bf16x8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s)
         qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + 16 * s + 8 * lh);
 
-    // ---- K/V staging plan: 8 pieces of 8 rows per tile and operand, waves take pieces w, w + 4 ---
-    int st_row[2];
-    int st_kchunk[2], st_vchunk[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = (wave + 4 * i) * 8 + (lane >> 3);
-        st_row[i] = row;
-        st_kchunk[i] = (lane & 7) ^ ((row >> 1) & 7);
-        st_vchunk[i] = (lane & 7) ^ (((row >> 1) & 1) << 2);
-    }
+    // ---- K/V staging plan: a tile is 8 pieces of 8 rows per operand; wave w moves piece w of K and V.
+    // Source pointers are kept per lane and advanced by a scalar stride per tile; only the ragged
+    // last tile needs its row index clamped (those keys are masked in the softmax; clamping keeps
+    // the V values finite).
+    const int st_row = wave * 8 + (lane >> 3);
+    const int st_kchunk = ((lane & 7) ^ ((st_row >> 1) & 7)) * 8;
+    const int st_vchunk = ((lane & 7) ^ (((st_row >> 1) & 1) << 2)) * 8;
+    const u16* st_src = base + (size_t)st_row * ld;
     auto stage = [&](int buf, int t) {
         char* sb = smem + buf * kStage;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int key = t * KV + st_row[i];
-            if (key > a.N - 1) key = a.N - 1;  // masked in the softmax; keeps V finite
-            const u16* src = base + (size_t)key * ld;
-            glds16(src + C + st_kchunk[i] * 8, sb + (wave + 4 * i) * 1024);
-            glds16(src + 2 * C + st_vchunk[i] * 8, sb + kTile + (wave + 4 * i) * 1024);
+        const u16* src = st_src + (size_t)t * (KV * ld);
+        if ((t + 1) * KV > a.N) {
+            int key = t * KV + st_row;
+            if (key > a.N - 1) key = a.N - 1;
+            src = base + (size_t)key * ld;
         }
+        glds16(src + C + st_kchunk, sb + wave * 1024);
+        glds16(src + 2 * C + st_vchunk, sb + kTile + wave * 1024);
     };
 
     // ---- per-lane LDS read offsets -------------------------------------------------------------
@@ -113,11 +115,8 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     float l_run = 0.f;
     const float c = a.c;
 
-    stage(0, 0);
-    for (int t = 0; t < a.ntiles; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (t + 1 < a.ntiles) stage((t + 1) & 1, t + 1);
+    // One key tile: S^T, online softmax, O^T update.
+    auto tile = [&](int t, bool masked) {
         const char* kb = smem + (t & 1) * kStage;
         const char* vb = kb + kTile;
 
@@ -133,7 +132,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
             s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, qf[s], s1, 0, 0, 0);
         }
         // register r of tile u <-> key  t*64 + 32 u + (r&3) + 8 (r>>2) + 4 lh
-        if ((t + 1) * KV > a.N) {
+        if (masked) {
+            // Only the ragged last tile takes this branch.  The empty asm keeps it a real (wave-uniform)
+            // branch: if-converted, the ~100 compare/select instructions would run for every tile.
+            asm volatile("" ::: "memory");
             const int kbase = t * KV + 4 * lh;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -143,6 +145,10 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
             }
         }
         // ---- online softmax ------------------------------------------------------------------
+        if constexpr (DIAG == 1) {  // timing diagnostic: skip the softmax arithmetic
+#pragma unroll
+            for (int r = 0; r < 16; ++r) l_run += s0[r] * 1e-30f;
+        } else {
         float mloc = s0[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s0[r]);
@@ -163,10 +169,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        }
 
         // ---- O^T += V^T P^T: P fragments straight from the S^T registers ----------------------
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
+        for (int u = 0; u < (DIAG == 2 ? 0 : 2); ++u) {  // DIAG 2: skip P V
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 union { bf16x8 v; uint32_t w[4]; } pf;
@@ -187,6 +194,15 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
                 }
             }
         }
+    };
+
+    stage(0, 0);
+    const int full_tiles = a.N / KV;  // tiles whose 64 keys are all valid
+    for (int t = 0; t < a.ntiles; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (DIAG != 3 || t == 0) { if (t + 1 < a.ntiles) stage((t + 1) & 1, t + 1); }  // DIAG 3: stage once
+        if (wave_active) tile(t, t >= full_tiles);
     }
 
     // ---- normalise and store: lane (query, half) holds d = 32 dt + 8 g + 4 lh + 0..3 -----------
@@ -211,7 +227,11 @@ __global__ __launch_bounds__(256, 2) void attention_kernel(const AttnArgs a) {
     }
 }
 
+int g_diag = 0;
+
 }  // namespace
+
+extern "C" void equss_dev_attn_diag(int d) { g_diag = d; }
 
 namespace equss {
 
@@ -229,7 +249,12 @@ int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale,
     a.c = scale * 1.4426950408889634f;
     const long grid = (long)a.nqb * B * H;
     if (grid > 0x7fffffffL) return fail(EQUSS_E_SHAPE, "attention_bf16: grid too large");
-    hipLaunchKernelGGL(attention_kernel, dim3((unsigned)grid), dim3(256), 2 * kStage, s, a);
+    switch (g_diag) {
+        case 1: hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
+        case 2: hipLaunchKernelGGL(attention_kernel<2>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
+        case 3: hipLaunchKernelGGL(attention_kernel<3>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
+        default: hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
+    }
     return check_launch("attention_kernel");
 }
 

@@ -49,8 +49,12 @@ __device__ __forceinline__ u16 f2bf(float x) {
 __device__ __forceinline__ float bf2f(u16 b) {
     return __builtin_bit_cast(float, (uint32_t)b << 16);
 }
+// two fp32 -> one dword of two bf16 (lo in bits 0..15): a single v_cvt_pk_bf16_f32
 __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
-    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
 template <int WIDTH>

@@ -29,7 +29,15 @@ struct Gemm8Args {
     const float* bias;
     void* out; int64_t ldo;
     int M, N, K, ntn, nostore;
+    // residual + LayerNorm epilogue (EPI_RESID_LN): x (M, N) fp32 is updated in place, ln receives
+    // LayerNorm(x) in bf16 (or is skipped when null)
+    float* x; int64_t ldx;
+    const float* gamma; const float* beta;
+    u16* ln; int64_t ld_ln;
+    float eps;
 };
+
+constexpr int EPI_RESID_LN = 100;  // internal epilogue id: x += acc + bias; ln = LayerNorm(x)
 
 __device__ __forceinline__ float erf_as(float x) {  // Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
     const float ax = fabsf(x);
@@ -97,7 +105,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     constexpr int RP = (kStageBytes / 8 >= 32 * ROWSTRIDE && TM >= 32) ? 32 : 16;
     constexpr int OCH = TN * 2 / 16;
     constexpr int PER_LANE = RP * OCH / 64;
-    constexpr int NST = EPI == EQUSS_EPI_F32 ? 0 : PER_LANE * (TM / RP);
+    constexpr int NST = (EPI == EQUSS_EPI_F32 || EPI == EPI_RESID_LN) ? 0 : PER_LANE * (TM / RP);
     static_assert((S - 1) * PW + NST <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -113,6 +121,9 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     const int x_len = q + (xcd < r ? 1 : 0);
     const int nslots = (gridDim.x + 7 - xcd) >> 3;
     if (slot >= x_len) return;
+    if (g.nostore >= 2 && (slot & 1)) {  // experiment: de-phase half of the CUs
+        for (int i = 0; i < g.nostore; ++i) __builtin_amdgcn_s_sleep(127);
+    }
     const int my_tiles = (x_len - slot + nslots - 1) / nslots;
     const int nk = g.K / BK;
     const int total = my_tiles * nk;
@@ -162,6 +173,15 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     // compiler wait for it, and with it (in-order retirement) for every prefetch issued before it.
     float* bias_s = reinterpret_cast<float*>(smem + S * kStageBytes);
     for (int i = tid; i < g.N; i += kThreads) bias_s[i] = g.bias ? g.bias[i] : 0.f;
+    float* gamma_s = bias_s + g.N;       // EPI_RESID_LN only (N == BN there)
+    float* beta_s = gamma_s + BN;
+    float2* red_s = reinterpret_cast<float2*>(beta_s + BN);  // BM rows x WN partial (sum, sum of squares)
+    if constexpr (EPI == EPI_RESID_LN) {
+        for (int i = tid; i < BN; i += kThreads) {
+            gamma_s[i] = g.ln ? g.gamma[i] : 1.f;
+            beta_s[i] = g.ln ? g.beta[i] : 0.f;
+        }
+    }
     __syncthreads();
     set_src(x_start + i_tile);
 #pragma unroll
@@ -175,10 +195,29 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
         const int m0 = (logical / g.ntn) * BM;
         const int n0 = (logical % g.ntn) * BN;
         f32x4 acc[NT][MT];  // element j <-> output column n + j
+        if constexpr (EPI == EPI_RESID_LN) {
+            // Start the accumulators from x + bias: the residual tile is fetched while the first K step
+            // is being waited for, straight into the accumulator registers, and the epilogue is left
+            // with stores only.
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = wn * TN + nt * 16 + fq * 4;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + n);
 #pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int m = m0 + wm * TM + mt * 16 + fr;
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
+                    o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
+                    acc[nt][mt] = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         for (int kt = 0; kt < nk; ++kt, ++step) {
             // this wave's pieces of stage `step` have landed once at most (issued - step - 1) younger
             // stages are outstanding (operations retire in order; epilogue stores in the queue only make
@@ -208,7 +247,71 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
             c_buf = c_buf + 1 == S ? 0 : c_buf + 1;
         }
         // ---- epilogue (stores only) ---------------------------------------------------------------------
-        if constexpr (EPI == EQUSS_EPI_F32) {
+        if constexpr (EPI == EPI_RESID_LN) {
+            // The accumulators already hold x + bias + A W^T: write x back (16 bytes per lane), then LayerNorm
+            // of the updated rows: a tile spans whole rows (BN == N), a row's 4 x NT x 4 values sit in the 4
+            // waves of one wm group, so the statistics are an in-lane sum, two shuffles and one small LDS
+            // exchange; the normalised rows leave as bf16 through the same wide-store path as below.
+            static_assert(EPI != EPI_RESID_LN || WN == 4, "row statistics assume four waves per row");
+            epi_mark = 0;
+            float s1[MT], s2[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wm * TM + mt * 16 + fr;
+                s1[mt] = 0.f; s2[mt] = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = wn * TN + nt * 16 + fq * 4;
+                    const f32x4 v = acc[nt][mt];
+                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+                    s1[mt] += (v.x + v.y) + (v.z + v.w);
+                    s2[mt] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                }
+                s1[mt] += __shfl_xor(s1[mt], 16, 64); s2[mt] += __shfl_xor(s2[mt], 16, 64);
+                s1[mt] += __shfl_xor(s1[mt], 32, 64); s2[mt] += __shfl_xor(s2[mt], 32, 64);
+                if (fq == 0) red_s[(wm * TM + mt * 16 + fr) * WN + wn] = make_float2(s1[mt], s2[mt]);
+            }
+            if (g.ln) {
+                const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
+                char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / 8);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // partial sums visible; ring slot no longer read
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int pass = 0; pass < TM / RP; ++pass) {
+#pragma unroll
+                    for (int ml = 0; ml < RP / 16; ++ml) {
+                        const int mt = pass * (RP / 16) + ml;
+                        const float2* pr = red_s + (wm * TM + mt * 16 + fr) * WN;
+                        const float2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+                        const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / BN);
+                        const float ex2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / BN);
+                        const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + g.eps);
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) {
+                            const int n = wn * TN + nt * 16 + fq * 4;
+                            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma_s + n);
+                            const f32x4 be = *reinterpret_cast<const f32x4*>(beta_s + n);
+                            const f32x4 v = acc[nt][mt];
+                            uint2 pk;
+                            pk.x = equss::pack_bf16((v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y);
+                            pk.y = equss::pack_bf16((v.z - mean) * rstd * ga.z + be.z, (v.w - mean) * rstd * ga.w + be.w);
+                            *reinterpret_cast<uint2*>(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
+                        }
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < PER_LANE; ++j) {
+                        const int idx = j * 64 + lane;
+                        const int row = idx / OCH, ch = idx % OCH;
+                        const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
+                        const int m = m0 + wm * TM + pass * RP + row;
+                        if (m < g.M) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * TN + ch * 8) = d;
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            }
+        } else if constexpr (EPI == EQUSS_EPI_F32) {
             // lane owns out[m][n .. n+3] as one 16-byte store
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
@@ -232,7 +335,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
             static_assert(RP * OCH % 64 == 0, "epilogue chunking");
             // A full tile issues exactly NST stores per wave, which lets the waits that follow leave them
             // in flight; the ragged last row-tile masks stores, so it falls back to the stricter wait.
-            const bool full = m0 + BM <= g.M && !g.nostore;
+            const bool full = m0 + BM <= g.M && g.nostore != 1;
             epi_mark = full ? issued : 0;
             const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
             char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / 8);
@@ -267,7 +370,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
                     const int row = idx / OCH, ch = idx % OCH;
                     const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                     const int m = m0 + wm * TM + pass * RP + row;
-                    if (g.nostore) { asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); continue; }
+                    if (g.nostore == 1) { asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); continue; }
                     if (full || m < g.M)
                         *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n0 + wn * TN + ch * 8) = d;
                 }
@@ -278,6 +381,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
 }
 
 int g_stages = 2;
+int g_prefer256 = 1;  // 256 x 256 tiles when N allows (131 flop/B instead of 96)
 int g_nostore = 0;
 
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
@@ -285,15 +389,16 @@ int launch_inst(const Gemm8Args& g, hipStream_t s) {
     const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
     const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
     constexpr int ring = S * (BM + BN) * BK * 2;
-    static_assert(ring + 16384 <= 163840, "LDS budget");
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
-    const int lds = ring + g.N * 4;
+    constexpr int extra = EPI == EPI_RESID_LN ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
+    static_assert(ring + extra <= 163840, "LDS budget");
+    const int lds = ring + (EPI == EPI_RESID_LN ? extra : g.N * 4);
     auto kern = gemm8_kernel<EPI, BM, BN, WM, WN, BK, S>;
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds) !=
-            hipSuccess)
-            return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: cannot reserve %d bytes of LDS", lds);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                ring + extra) != hipSuccess)
+            return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: cannot reserve %d bytes of LDS", ring + extra);
         attr_done = true;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, g);
@@ -311,7 +416,7 @@ int launch_shape(const Gemm8Args& g, hipStream_t s) {
 
 template <int EPI>
 int launch(Gemm8Args& g, hipStream_t s) {
-    if (g.N % 384 == 0) {
+    if (g.N % 384 == 0 && !(g_prefer256 && g.N % 256 == 0)) {
         g.ntn = g.N / 384;
         return launch_shape<EPI, 128, 384, 2, 4>(g, s);
     }
@@ -333,6 +438,7 @@ int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const flo
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
     g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.ntn = 0; g.nostore = g_nostore;
+    g.x = nullptr; g.ldx = 0; g.gamma = nullptr; g.beta = nullptr; g.ln = nullptr; g.ld_ln = 0; g.eps = 0.f;
     switch (epilogue) {
         case EQUSS_EPI_BF16: return launch<EQUSS_EPI_BF16>(g, s);
         case EQUSS_EPI_GELU_BF16: return launch<EQUSS_EPI_GELU_BF16>(g, s);
@@ -342,6 +448,21 @@ int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const flo
     }
 }
 
+// x (M, N) fp32 += A W^T + bias, then ln = LayerNorm(x) * gamma + beta in bf16 (ln may be null).
+// Needs N == 384 so that one tile holds whole rows.
+bool gemm8_resid_ln_supports(int N, int K) { return N == 384 && K % 64 == 0; }
+
+int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
+                   const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, int N, int K, float eps,
+                   hipStream_t s) {
+    Gemm8Args g;
+    g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
+    g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
+    g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1; g.nostore = 0;
+    g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
+    return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);
+}
+
 }  // namespace equss
 
-extern "C" void equss_dev_gemm_stages(int s) { g_stages = s & 15; g_nostore = (s >> 4) & 1; }  // tuning knob, not part of the ABI
+extern "C" void equss_dev_gemm_stages(int s) { g_stages = s & 7; g_prefer256 = (s >> 3) & 1; g_nostore = s >> 4; }  // tuning knob, not part of the ABI

@@ -6,6 +6,10 @@ namespace equss {
 int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
               int M, int N, int K, int epilogue, hipStream_t s);
 int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s);
+bool gemm8_resid_ln_supports(int N, int K);
+int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
+                   const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, int N, int K, float eps,
+                   hipStream_t s);
 }  // namespace equss
 
 namespace {
@@ -263,16 +267,46 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         rc = (call);                          \
     }                                         \
     if (rc) return rc;
-        EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln1_g, k.ln1_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        // With C == 384 the residual GEMMs also emit the LayerNorm their consumer needs (norm2 of this
+        // block after proj, norm1 of the next block after fc2), so only block 0's norm1 and the final
+        // norm run as standalone kernels.
+        const bool fuse = equss::gemm8_resid_ln_supports(C, C);
+        const bool last = i + 1 == vit->depth;
+        if (!fuse || i == 0) {
+            EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln1_g, k.ln1_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        }
         EQUSS_STEP(EQUSS_K_GEMM_QKV, equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))
         EQUSS_STEP(EQUSS_K_ATTENTION, equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))
-        EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))
-        EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        if (fuse) {
+            EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm8_resid_ln(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
+        } else {
+            EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))
+            EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        }
         EQUSS_STEP(EQUSS_K_GEMM_FC1, equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))
-        EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))
+        if (fuse) {
+            const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
+            EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm8_resid_ln(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, C, rows, C, 4 * C, 1e-6f, s))
+        } else {
+            EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))
+        }
     }
     EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, vit->norm_g, vit->norm_b, feat_bf16, ld_feat, feat_f32, rows, C, N, 1e-6f, s))
     return EQUSS_OK;
+}
+
+extern "C" int equss_gemm_resid_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                                        float* x, int64_t ldx, const float* gamma, const float* beta, void* ln_out,
+                                        int64_t ld_ln, int M, int N, int K, float eps, void* stream) {
+    if (!A || !W || !x || (ln_out && (!gamma || !beta))) return equss::fail(EQUSS_E_NULL, "gemm_resid_ln: null pointer argument");
+    if (M <= 0 || K <= 0) return equss::fail(EQUSS_E_SHAPE, "gemm_resid_ln: M=%d K=%d must be positive", M, K);
+    if (!equss::gemm8_resid_ln_supports(N, K))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "gemm_resid_ln: N=%d K=%d (N must be 384, K a multiple of 64)", N, K);
+    if (lda < K || ldw < K || ldx < N || (ln_out && ld_ln < N) || (lda % 8) || (ldw % 8) || (ldx % 4) || (ld_ln % 8) ||
+        ((uintptr_t)A % 16) || ((uintptr_t)W % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
+        return equss::fail(EQUSS_E_ALIGN, "gemm_resid_ln: operands must be 16-byte aligned with padded leading dimensions");
+    return equss::gemm8_resid_ln(A, lda, W, ldw, bias, x, ldx, gamma, beta, ln_out, ld_ln, M, N, K, eps,
+                                 reinterpret_cast<hipStream_t>(stream));
 }
 
 // code = [f | relu(f W2a^T + b2a)] [W1 | W2b]^T + (b1 + b2b)   (model/dino_pqgo.py:104-112,:127-128)

@@ -18,7 +18,7 @@ EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3, 4
 EXPORTED_SYMBOLS = [
     "equss_abi_version", "equss_last_error", "equss_profile_enable", "equss_profile_read",
     "equss_pq_workspace_bytes", "equss_pq_assign", "equss_pq_prob",
-    "equss_layernorm_bf16", "equss_gemm_bf16", "equss_attention_bf16",
+    "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
 ]
@@ -67,6 +67,9 @@ def _declare(lib):
     lib.equss_layernorm_bf16.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_int, c_int, c_int, c_f, c_vp]
     lib.equss_gemm_bf16.restype = c_int
     lib.equss_gemm_bf16.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_gemm_resid_ln_bf16.restype = c_int
+    lib.equss_gemm_resid_ln_bf16.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64,
+                                             c_int, c_int, c_int, c_f, c_vp]
     lib.equss_attention_bf16.restype = c_int
     lib.equss_attention_bf16.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_f, c_vp]
     lib.equss_patch_workspace_bytes.restype = c_sz
@@ -247,6 +250,20 @@ def gemm_bf16(a, w, bias, epilogue, out=None):
                              m, n, k, int(epilogue), _stream(a))
     _check(rc, "equss_gemm_bf16")
     return out
+
+
+def gemm_resid_ln_bf16(a, w, bias, x, gamma=None, beta=None, eps=1e-6, want_ln=True):
+    """x += a @ w.T + bias (fp32, in place); returns LayerNorm(x) * gamma + beta in bf16 (or None)."""
+    lib = load_library()
+    _need_cuda(a, w, bias, x, gamma, beta)
+    m, k = a.shape
+    n = w.shape[0]
+    ln = torch.empty((m, n), dtype=torch.bfloat16, device=a.device) if want_ln else None
+    rc = lib.equss_gemm_resid_ln_bf16(_ptr(a), a.stride(0), _ptr(w), w.stride(0), _ptr(bias), _ptr(x), x.stride(0),
+                                      _ptr(gamma), _ptr(beta), _ptr(ln), n if ln is None else ln.stride(0), m, n, k,
+                                      float(eps), _stream(a))
+    _check(rc, "equss_gemm_resid_ln_bf16")
+    return ln
 
 
 def attention_bf16(qkv, batch, tokens, heads, scale, out=None):

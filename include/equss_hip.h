@@ -137,6 +137,17 @@ int equss_layernorm_bf16(const float* x, int64_t ld_x, const float* gamma, const
 int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream);
 
+/* Residual update fused with the LayerNorm that follows it:
+ *   x += A * W^T + bias            (vision_transformer.py:110 / :111, fp32 residual stream, in place)
+ *   ln_out = LayerNorm(x) * gamma + beta in bf16   (the norm2 of the same block, :111, or the norm1 of
+ *            the next block, :107); ln_out may be NULL to skip it.
+ *   A (M, K) bf16; W (N, K) bf16; x (M, N) fp32 with leading dimension ldx; ln_out (M, N) bf16.
+ * N must be 384 (one workgroup tile then holds whole rows); other widths use equss_gemm_bf16 with
+ * EQUSS_EPI_RESID_F32 followed by equss_layernorm_bf16. */
+int equss_gemm_resid_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
+                             float* x, int64_t ldx, const float* gamma, const float* beta, void* ln_out,
+                             int64_t ld_ln, int M, int N, int K, float eps, void* stream);
+
 /* Multi-head self-attention softmax(q k^T * scale) v without materialising the (N x N) matrix
  * (vision_transformer.py:81-88; the attention matrix it returns is discarded by
  * dino_featurizer.py:76-80).

@@ -138,7 +138,8 @@ def test_training_step_runs_and_gives_gradients(pkg, dev):
     pos = pkg.synth.synth_images(2, 64, 64, seed=2).to(dev)
     label = pkg.synth.synth_labels(2, 64, 64, cfg["num_classes"], seed=1).to(dev)
     before = m.model.vq_blocks[0].quantizers[0].embedding.weight.detach().clone()
-    total, out, preds, feat_vqs = m(img, img, label, img_pos=pos, it=0)
+    with torch.enable_grad():
+        total, out, preds, feat_vqs = m(img, img, label, img_pos=pos, it=0)
     assert not torch.equal(before, m.model.vq_blocks[0].quantizers[0].embedding.weight)  # first-call re-init (:589-609)
     for k in ("vq-loss", "loss", "linear-loss", "cluster-loss", "codebook-usage", "stego-loss", "end_time"):
         assert k in out, k

@@ -152,3 +152,29 @@ def test_patch_tokens(native, dev):
     ref = torch.cat((cls.expand(b, 1, c), ref), dim=1) + pos
     x = native.patch_tokens(img.to(dev), _bf(w.reshape(c, -1)).to(dev), bias.to(dev), cls.to(dev), pos.to(dev), p)
     torch.testing.assert_close(x.cpu().reshape(b, n + 1, c), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("m,k", [(300, 384), (128, 1536), (1000, 384)])
+def test_gemm_residual_layernorm_fused(m, k, native, dev):
+    """x += a w^T + b; ln = LayerNorm(x): against fp32 torch on bf16-rounded operands."""
+    g = _rng(m + k)
+    n = 384
+    a = _bf(torch.from_numpy(g.standard_normal((m, k)).astype(np.float32)))
+    w = _bf(torch.from_numpy((g.standard_normal((n, k)) / math.sqrt(k)).astype(np.float32)))
+    bias = torch.from_numpy(g.standard_normal(n).astype(np.float32))
+    x0 = torch.from_numpy((2 * g.standard_normal((m, n)) + 0.5).astype(np.float32))
+    gamma = torch.from_numpy((1 + 0.1 * g.standard_normal(n)).astype(np.float32))
+    beta = torch.from_numpy((0.1 * g.standard_normal(n)).astype(np.float32))
+    x_ref = x0.double() + a.double() @ w.double().t() + bias.double()
+    ln_ref = F.layer_norm(x_ref, (n,), gamma.double(), beta.double(), 1e-6)
+    x = x0.clone().to(dev)
+    ln = native.gemm_resid_ln_bf16(a.to(dev), w.to(dev), bias.to(dev), x, gamma.to(dev), beta.to(dev), 1e-6)
+    torch.cuda.synchronize()
+    assert (x.cpu().double() - x_ref).abs().max() < 1e-4
+    torch.testing.assert_close(ln.cpu().float(), ln_ref.float(), rtol=1e-2, atol=1e-2)
+    assert (ln.cpu().double() - ln_ref).abs().mean() < 2e-3
+    x2 = x0.clone().to(dev)
+    assert native.gemm_resid_ln_bf16(a.to(dev), w.to(dev), bias.to(dev), x2, want_ln=False) is None
+    assert torch.equal(x2, x)
+    with pytest.raises(ValueError):
+        native.gemm_resid_ln_bf16(a.to(dev), _bf(torch.zeros(256, k)).to(dev), None, torch.zeros(m, 256, device=dev), want_ln=False)
