@@ -9,6 +9,7 @@ Reference class                                   -> here
   model/dino_pqgo.py DIONPQGO / Codebook / ProductQuantizerWrapper -> pqgo.*
   model/quantizer.py VectorQuantizer / EMAVectorQuantizer / ...    -> quantizer.*
   model/evaluator.py UnSegEvaluator / ClusterLookup  -> evaluator.*
+  model/metric.py UnSegMetrics                       -> metric.*
   wrapper/PQGOWrapper.py PQGOWrapper, build.py build_model -> wrapper.*
   utils/dist_utils.py                                -> dist_utils.*
 """
@@ -17,9 +18,10 @@ from . import dist_utils, native  # noqa: F401
 from .featurizer import DinoFeaturizer, VisionTransformer  # noqa: F401
 from .pqgo import DIONPQGO, Codebook, ProductQuantizerWrapper, STEGOLoss  # noqa: F401
 from .evaluator import UnSegEvaluator, ClusterLookup  # noqa: F401
+from .metric import UnSegMetrics  # noqa: F401
 from .wrapper import PQGOWrapper, build_model  # noqa: F401
 from . import quantizer  # noqa: F401
 
 __all__ = ["configs", "synth", "native", "dist_utils", "quantizer", "DinoFeaturizer", "VisionTransformer",
            "DIONPQGO", "Codebook", "ProductQuantizerWrapper", "STEGOLoss", "UnSegEvaluator", "ClusterLookup",
-           "PQGOWrapper", "build_model"]
+           "UnSegMetrics", "PQGOWrapper", "build_model"]

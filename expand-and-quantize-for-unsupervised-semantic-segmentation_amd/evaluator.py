@@ -1,17 +1,20 @@
 """Linear and cluster probes (model/evaluator.py:11-111) with the reference's parameter names
 (``linear_probe.{weight,bias}``, ``cluster_probe.clusters``).
 
-The probes sit next to the hot path (they consume its output inside the eval loop) but are not
-part of it: this module follows the reference's op sequence with stock device ops so that the
-wrapper's return tuple and losses are complete.  The (B, D, H, W) bilinear up-sampling of the
-D = 1024 feature map costs 420 MB fp32 per 320x320 image, so large batches are processed in
-slices of a few images to bound memory.
+The probes consume the hot path's output inside the eval loop (wrapper/PQGOWrapper.py:95).  The
+reference up-samples the D = 1024 feature map bilinearly to the label size first (420 MB fp32 per
+320x320 image).  Without autograd (the eval loop) the HIP path evaluates both probes at low
+resolution and interpolates their outputs per pixel, which is the same function without that
+tensor.  When gradients are needed (the probes are trained through this forward) the reference's
+op sequence runs with stock device ops, in slices of a few images when no graph is recorded.
 """
 from typing import Optional
 
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from . import native
 
 __all__ = ["UnSegEvaluator", "ClusterLookup"]
 
@@ -45,7 +48,8 @@ class UnSegEvaluator(nn.Module):
         self.linear_probe = nn.Conv2d(embed_dim, num_classes, kernel_size=1, stride=1)
         self.cluster_probe = ClusterLookup(embed_dim, num_classes + extra_classes)
         self.linear_loss = nn.CrossEntropyLoss()
-        self.slice_images = 4  # images per up-sampling slice in eval
+        self.slice_images = 4  # images per up-sampling slice of the stock-op path without a graph
+        self.use_hip = True    # False forces the stock-op path (for comparisons)
 
     def forward(self, out: torch.Tensor, img: torch.Tensor, label: Optional[torch.Tensor] = None,
                 is_crf: bool = False):
@@ -53,6 +57,10 @@ class UnSegEvaluator(nn.Module):
         if is_crf:
             raise NotImplementedError("dense-CRF post-processing (pydensecrf on the host) is outside this build")
         assert label is not None
+        needs_graph = torch.is_grad_enabled() and (
+            out.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if out.is_cuda and self.use_hip and not needs_graph:
+            return self._forward_hip(out, label)
         b = out.shape[0]
         step = b if (self.training and torch.is_grad_enabled()) else self.slice_images
         lin_logits, lin_preds, clu_preds, clu_inner = [], [], [], []
@@ -78,3 +86,12 @@ class UnSegEvaluator(nn.Module):
         logit_flat = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
         linear_loss = self.linear_loss(logit_flat[mask], label_flat[mask]).mean()
         return linear_loss, linear_preds, cluster_loss, cluster_preds
+
+    def _forward_hip(self, out: torch.Tensor, label: torch.Tensor):
+        b, d, h, w = out.shape
+        rows = out.permute(0, 2, 3, 1).reshape(b * h * w, d)  # a view when `out` is token-major underneath
+        n_lin, n_clu = self.num_classes, self.cluster_probe.n_classes
+        probes, bias = native.pack_probes(self.linear_probe.weight.detach(), self.linear_probe.bias.detach(),
+                                          self.cluster_probe.clusters.detach())
+        lin, clu, losses = native.probe_eval(rows.float(), probes, bias, label.long(), b, h, w, n_lin, n_clu)
+        return losses[0], lin, losses[1], clu

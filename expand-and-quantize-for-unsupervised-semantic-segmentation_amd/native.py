@@ -21,6 +21,7 @@ EXPORTED_SYMBOLS = [
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
+    "equss_probe_workspace_bytes", "equss_probe_eval",
 ]
 
 
@@ -84,6 +85,11 @@ def _declare(lib):
                                       c_int, c_int, c_int, c_vp]
     lib.equss_expand_head.restype = c_int
     lib.equss_expand_head.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]
+    lib.equss_probe_workspace_bytes.restype = c_sz
+    lib.equss_probe_workspace_bytes.argtypes = [c_int] * 5
+    lib.equss_probe_eval.restype = c_int
+    lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
 
 
 def load_library():
@@ -144,7 +150,7 @@ def _workspace(device, nbytes, tag):
 
 
 KERNEL_CLASSES = ["patch", "layernorm", "gemm_qkv", "attention", "gemm_proj", "gemm_fc1", "gemm_fc2",
-                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign"]
+                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign", "probe_table", "probe_pixels"]
 
 
 def profile_enable(max_pairs):
@@ -338,3 +344,50 @@ def expand_head(fh, w2a, b2a, w_cat, b_cat, out_dim):
                                out_dim, _stream(fh))
     _check(rc, "equss_expand_head")
     return code
+
+
+# ------------------------------------------------------------------------------------------------
+# Probes of the eval loop
+# ------------------------------------------------------------------------------------------------
+PROBE_SLOTS = 32  # classes per probe the kernel's table holds
+
+
+def pack_probes(linear_weight, linear_bias, clusters):
+    """(64, D) fp32 probe matrix and (64,) bias for probe_eval: rows [0, C) are the linear probe's
+    1x1-conv weights, rows [32, 32 + C') the clusters normalised as evaluator.py:95 does."""
+    n_lin, n_clu = linear_weight.shape[0], clusters.shape[0]
+    if n_lin > PROBE_SLOTS or n_clu > PROBE_SLOTS:
+        raise ValueError(f"probe_eval holds at most {PROBE_SLOTS} classes per probe, got {n_lin} / {n_clu}")
+    d = clusters.shape[1]
+    probes = torch.zeros(2 * PROBE_SLOTS, d, dtype=torch.float32, device=clusters.device)
+    probes[:n_lin] = linear_weight.reshape(n_lin, d).float()
+    probes[PROBE_SLOTS:PROBE_SLOTS + n_clu] = torch.nn.functional.normalize(clusters.float(), dim=1)
+    bias = torch.zeros(2 * PROBE_SLOTS, dtype=torch.float32, device=clusters.device)
+    bias[:n_lin] = linear_bias.float()
+    return probes, bias
+
+
+def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster):
+    """feat_rows (batch*h*w, D) fp32 token-major, label (batch, H, W) int64 ->
+    (linear_preds, cluster_preds) (batch, H, W) int64 and losses (2,) fp32 = [linear CE, cluster loss]."""
+    _need_cuda(feat_rows, probes, bias, label)
+    if feat_rows.dtype != torch.float32 or feat_rows.dim() != 2 or feat_rows.shape[0] != batch * h * w:
+        raise ValueError("probe_eval: feat_rows must be (batch*h*w, D) float32")
+    if feat_rows.stride(1) != 1 or feat_rows.stride(0) % 4 or feat_rows.data_ptr() % 16:
+        feat_rows = feat_rows.contiguous()
+    if label.dtype != torch.int64 or label.dim() != 3 or label.shape[0] != batch:
+        raise ValueError("probe_eval: label must be (batch, H, W) int64")
+    label = label.contiguous()
+    H, W = int(label.shape[1]), int(label.shape[2])
+    dev = feat_rows.device
+    lin = torch.empty((batch, H, W), dtype=torch.int64, device=dev)
+    clu = torch.empty((batch, H, W), dtype=torch.int64, device=dev)
+    losses = torch.empty(2, dtype=torch.float32, device=dev)
+    lib = load_library()
+    nbytes = lib.equss_probe_workspace_bytes(batch, h, w, H, W)
+    ws = _workspace(dev, nbytes, "probe")
+    _check(lib.equss_probe_eval(_ptr(feat_rows), feat_rows.stride(0), _ptr(probes), _ptr(bias), _ptr(label),
+                                _ptr(lin), _ptr(clu), _ptr(losses), _ptr(ws), ws.numel(),
+                                batch, h, w, feat_rows.shape[1], H, W, n_linear, n_cluster, _stream(feat_rows)),
+           "equss_probe_eval")
+    return lin, clu, losses

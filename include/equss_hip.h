@@ -78,7 +78,9 @@ enum {
     EQUSS_K_HEAD_GEMM2 = 8,
     EQUSS_K_PQ_PREP = 9,
     EQUSS_K_PQ_ASSIGN = 10,
-    EQUSS_K_COUNT = 11
+    EQUSS_K_PROBE_TABLE = 11,  /* low-resolution probe products + neighbour Gram entries */
+    EQUSS_K_PROBE_PIXELS = 12, /* per-pixel interpolation, arg-max, losses */
+    EQUSS_K_COUNT = 13
 };
 int equss_profile_enable(int max_pairs);
 int equss_profile_read(double* ms, int64_t* launches, int reset);
@@ -203,6 +205,31 @@ int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, v
  *   code (rows, D) fp32 out. */
 int equss_expand_head(void* fh, const void* w2a, const float* b2a, const void* w_cat,
                       const float* b_cat, float* code, int rows, int C, int D, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Linear + cluster probes of the eval loop: UnSegEvaluator.forward with is_crf = False and
+ * ClusterLookup.forward with alpha = None (model/evaluator.py:46-82, :93-111), called once per batch
+ * by wrapper/PQGOWrapper.py:95.  The reference up-samples the (B, D, h, w) map bilinearly
+ * (align_corners = False) to the label size and evaluates both probes per pixel; here the probes
+ * are evaluated at (h, w) and their outputs interpolated, which is the same function of the inputs
+ * (both probes are linear in the feature; the cosine's denominator comes from the neighbours' Gram
+ * entries), so the up-sampled map is never written.
+ *   feat     (B*h*w, D) fp32 token-major, leading dimension ld_feat (multiple of 4)
+ *   probes   (64, D) fp32: rows [0, n_linear) = linear_probe.weight, rows [32, 32 + n_cluster) =
+ *            cluster_probe.clusters normalised to unit length (:95), all other rows zero
+ *   bias     (64) fp32: linear_probe.bias in [0, n_linear), zero elsewhere
+ *   label    (B, H, W) int64; pixels with a label outside [0, n_linear) are left out of the
+ *            cross-entropy (:72-80)
+ *   linear_preds, cluster_preds (B, H, W) int64 out: first arg-max over classes (:68, :70)
+ *   losses   (2) fp32 out: [0] mean cross-entropy over labelled pixels, [1] -mean max cosine (:106)
+ *   workspace equss_probe_workspace_bytes() bytes, 256-byte aligned
+ * D % 8 == 0; 1 <= n_linear, n_cluster <= 32.  All arithmetic is fp32.
+ * ------------------------------------------------------------------------------------------- */
+size_t equss_probe_workspace_bytes(int B, int h, int w, int H, int W);
+int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
+                     const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds, float* losses,
+                     void* workspace, size_t workspace_bytes, int B, int h, int w, int D, int H, int W,
+                     int n_linear, int n_cluster, void* stream);
 
 #ifdef __cplusplus
 }

@@ -24,6 +24,7 @@ __all__ = [
     "vit_last_feat", "dino_featurizer", "expansion_head", "codebook_forward", "pq_forward",
     "pqgo_forward", "cluster_lookup", "evaluator_forward", "wrapper_forward",
     "vector_quantizer_forward", "ema_vector_quantizer_eval", "histogram_count", "pq_top2_gap",
+    "evaluator_top2_gap", "metrics_confusion", "metrics_compute",
 ]
 
 State = Dict[str, torch.Tensor]
@@ -310,6 +311,61 @@ def wrapper_forward(sd: State, img: torch.Tensor, label: torch.Tensor, cfg: dict
     output["cluster-loss"] = cluster_loss
     total = model_loss + linear_loss + cluster_loss
     return total, output, (linear_preds, cluster_preds), feat_vqs, z_index
+
+
+def evaluator_top2_gap(sd: State, out: torch.Tensor, label_hw, prefix: str = "evaluator."):
+    """fp64 evaluation of both probes (evaluator.py:53-70, :95-98): arg-max and the gap between the
+    largest and second-largest class score per output pixel.  Tests use the gap to tell a genuine
+    mismatch from a near-tie that fp32 rounding order may resolve either way."""
+    o = out.double()
+    if tuple(o.shape[-2:]) != tuple(label_hw):
+        o = F.interpolate(o, tuple(label_hw), mode="bilinear", align_corners=False)
+    logits = F.conv2d(o, sd[prefix + "linear_probe.weight"].double(), sd[prefix + "linear_probe.bias"].double())
+    inner = torch.einsum("bchw,nc->bnhw", F.normalize(o, dim=1),
+                         F.normalize(sd[prefix + "cluster_probe.clusters"].double(), dim=1))
+    res = []
+    for score in (logits, inner):
+        top = score.topk(2, dim=1)
+        res.append((top.indices[:, 0], top.values[:, 0] - top.values[:, 1]))
+    return res[0], res[1]
+
+
+def metrics_confusion(preds: torch.Tensor, label: torch.Tensor, num_classes: int, extra_classes: int = 0):
+    """UnSegMetrics.update, metric.py:45-58: confusion[pred, label] over pixels whose label AND
+    prediction lie in [0, num_classes)."""
+    preds, label = preds.reshape(-1), label.reshape(-1)
+    n_pred = num_classes + extra_classes
+    mask = (label >= 0) & (label < num_classes) & (preds >= 0) & (preds < num_classes)
+    conf = torch.zeros(n_pred, num_classes, dtype=torch.long)
+    for p, l in zip(preds[mask].tolist(), label[mask].tolist()):
+        conf[p, l] += 1
+    return conf
+
+
+def metrics_compute(confusion: torch.Tensor, compute_hungarian: bool, num_classes: int, extra_classes: int = 0):
+    """UnSegMetrics.compute, metric.py:60-98, on one rank: (iou %, accuracy %, histogram, assignments)."""
+    from scipy.optimize import linear_sum_assignment
+    import numpy as np
+    if compute_hungarian:
+        assignments = linear_sum_assignment(confusion, maximize=True)
+        if extra_classes == 0:
+            histogram = confusion[np.argsort(assignments[1]), :]
+        else:
+            assignments_t = linear_sum_assignment(confusion.t(), maximize=True)
+            histogram = confusion[assignments_t[1], :]
+            missing = list(set(range(num_classes + extra_classes)) - set(assignments[0]))
+            histogram = torch.cat([histogram, confusion[missing, :].sum(0, keepdim=True)], dim=0)
+            histogram = torch.cat([histogram, torch.zeros(num_classes + 1, 1)], dim=1)
+    else:
+        assignments = (torch.arange(num_classes).unsqueeze(1), torch.arange(num_classes).unsqueeze(1))
+        histogram = confusion
+    tp = torch.diag(histogram)
+    fp = torch.sum(histogram, dim=0) - tp
+    fn = torch.sum(histogram, dim=1) - tp
+    iou = tp / (tp + fp + fn)
+    iou = iou[~torch.isnan(iou)].mean()
+    accuracy = torch.sum(tp) / torch.sum(histogram)
+    return 100 * iou, 100 * accuracy, histogram, assignments
 
 
 # --------------------------------------------------------------------------------------------

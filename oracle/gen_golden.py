@@ -282,11 +282,88 @@ def main():
     assert hr == ho, (hr, ho)
     manifest["histogram_case"] = {"count": cnt.tolist(), "expect": hr}
 
+    probe_and_metric_fixtures(manifest, tmp)
+
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print(json.dumps(manifest["near_tie_census_g5"]))
     print("golden fixtures written to", OUT)
 
 
+def probe_and_metric_fixtures(manifest, tmp):
+    """G9: UnSegEvaluator alone on seeded features (integer and fractional up-sampling factors, and no
+    up-sampling); G10: UnSegMetrics.  `--probes-only` regenerates just these two."""
+    _stub_missing_modules()
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from model.evaluator import UnSegEvaluator
+    from model.metric import UnSegMetrics
+    g9 = {}
+    cases = {"x8": (2, 1024, 5, 6, 40, 48, 27), "frac": (2, 64, 7, 5, 45, 33, 27), "same": (1, 64, 9, 11, 9, 11, 5)}
+    for name, (b, d, h, w, hh, ww, ncls) in cases.items():
+        rng = np.random.Generator(np.random.PCG64(90 + len(name)))
+        out = torch.from_numpy(rng.standard_normal((b, h, w, d)).astype(np.float32)).permute(0, 3, 1, 2).contiguous()
+        label = torch.from_numpy(rng.integers(-1, ncls, size=(b, hh, ww)).astype(np.int64))
+        ev = UnSegEvaluator(d, ncls, 0).eval()
+        sd = {"evaluator.linear_probe.weight": torch.from_numpy((0.05 * rng.standard_normal((ncls, d, 1, 1))).astype(np.float32)),
+              "evaluator.linear_probe.bias": torch.from_numpy((0.1 * rng.standard_normal(ncls)).astype(np.float32)),
+              "evaluator.cluster_probe.clusters": torch.from_numpy(rng.standard_normal((ncls, d)).astype(np.float32))}
+        ev.load_state_dict({k[len("evaluator."):]: v for k, v in sd.items()}, strict=True)
+        lin_loss, lin_p, clu_loss, clu_p = ev(out, None, label=label)
+        o = oracle.evaluator_forward(sd, out, label, ncls)
+        _eq(o[0], lin_loss, f"G9 {name} linear loss")
+        _eq(o[1], lin_p, f"G9 {name} linear preds")
+        _eq(o[2], clu_loss, f"G9 {name} cluster loss")
+        _eq(o[3], clu_p, f"G9 {name} cluster preds")
+        (i_lin, gap_lin), (i_clu, gap_clu) = oracle.evaluator_top2_gap(sd, out, (hh, ww))
+        g9.update({f"{name}_meta": np.array([b, d, h, w, hh, ww, ncls], dtype=np.int64), f"{name}_seed": np.int64(90 + len(name)),
+                   f"{name}_linear_preds": lin_p.numpy().astype(np.int16), f"{name}_cluster_preds": clu_p.numpy().astype(np.int16),
+                   f"{name}_linear_gap64": gap_lin.numpy().astype(np.float32), f"{name}_cluster_gap64": gap_clu.numpy().astype(np.float32),
+                   f"{name}_fp64_agrees": np.array([torch.equal(i_lin, lin_p), torch.equal(i_clu, clu_p)]),
+                   f"{name}_linear_loss": np.float32(lin_loss), f"{name}_cluster_loss": np.float32(clu_loss)})
+    manifest["files"]["g9_evaluator"] = _save("g9_evaluator", **g9)
+
+    g10 = {}
+    cwd = os.getcwd()
+    os.chdir(tmp)  # the reference's compute() writes ./class_matrix/... as a side effect
+    try:
+        for name, (ncls, extra, hung) in {"cluster": (27, 0, True), "linear": (27, 0, False), "extra": (6, 3, True)}.items():
+            rng = np.random.Generator(np.random.PCG64(100 + ncls + extra + int(hung)))
+            label = torch.from_numpy(rng.integers(-1, ncls, size=(2, 48, 48)).astype(np.int64))
+            # predictions correlated with a permutation of the labels so that the assignment matters
+            perm = torch.from_numpy(rng.permutation(ncls))
+            noise = torch.from_numpy(rng.integers(0, ncls + extra, size=(2, 48, 48)).astype(np.int64))
+            keep = torch.from_numpy(rng.random((2, 48, 48)) < 0.6)
+            preds = torch.where(keep & (label >= 0), perm[label.clamp(min=0)], noise)
+            m = UnSegMetrics(ncls, extra, hung, torch.device("cpu"))
+            m.update(preds[:1], label[:1])
+            m.update(preds[1:], label[1:])
+            res = m.compute(name)
+            conf = oracle.metrics_confusion(preds, label, ncls, extra)
+            _eq(conf, m.confusion_matrix, f"G10 {name} confusion")
+            iou, acc, hist, assign = oracle.metrics_compute(conf, hung, ncls, extra)
+            _eq(iou, res["iou"], f"G10 {name} iou")
+            _eq(acc, res["accuracy"], f"G10 {name} accuracy")
+            mapped = m.map_clusters(torch.arange(ncls + extra)) if hung else torch.arange(ncls)
+            g10.update({f"{name}_meta": np.array([ncls, extra, int(hung)], dtype=np.int64), f"{name}_preds": preds.numpy().astype(np.int16),
+                        f"{name}_label": label.numpy().astype(np.int16), f"{name}_confusion": m.confusion_matrix.numpy(),
+                        f"{name}_iou": np.float32(res["iou"]), f"{name}_accuracy": np.float32(res["accuracy"]),
+                        f"{name}_histogram": m.histogram.numpy().astype(np.float64), f"{name}_map": mapped.numpy().astype(np.int64)})
+    finally:
+        os.chdir(cwd)
+    manifest["files"]["g10_metrics"] = _save("g10_metrics", **g10)
+
+
+def probes_only():
+    torch.manual_seed(0)
+    torch.set_grad_enabled(False)
+    with open(os.path.join(OUT, "manifest.json")) as f:
+        manifest = json.load(f)
+    probe_and_metric_fixtures(manifest, tempfile.mkdtemp(prefix="equss_golden_"))
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    print("probe / metric fixtures written to", OUT)
+
+
 if __name__ == "__main__":
-    main()
+    probes_only() if "--probes-only" in sys.argv else main()
