@@ -73,7 +73,9 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--res", type=int, default=320)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--gemm-variant", type=int, default=-1, help="developer knob: GEMM kernel variant; -1 = library default")
+    ap.add_argument("--cfg", choices=["s", "b"], default="s",
+                    help="s = ViT-S/8, D=1024, 8x256 PQ (the headline workload); b = ViT-B/8, D=2048, 16x512 PQ "
+                         "(use with --res 768 --batch 2..4)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -91,9 +93,7 @@ def main():
         dist.init_process_group(backend="nccl")  # RCCL over xGMI on ROCm
 
     pkg = importlib.import_module(PKG)
-    if args.gemm_variant >= 0:
-        pkg.native.load_library().equss_dev_gemm_variant(args.gemm_variant)
-    cfg = pkg.configs.S_CFG
+    cfg = pkg.configs.S_CFG if args.cfg == "s" else pkg.configs.B_CFG
     state = pkg.synth.synth_pqgo_state(cfg, seed=1234)
     model = pkg.build_model(cfg)
     model.load_state_dict(state, strict=True)
@@ -208,7 +208,9 @@ def main():
         "vs_baseline": None,
         "dtype": "bf16",
         "data": "synthetic",
-        "config": {"workload": f"DINO ViT-S/8 + expansion head (D=1024) + 8-subspace PQ (K=256), "
+        "config": {"workload": f"DINO {'ViT-S/8' if args.cfg == 's' else 'ViT-B/8'} + expansion head "
+                               f"(D={cfg['model']['vq']['embed_dims'][0]}) + {cfg['model']['vq']['num_pq'][0]}-subspace PQ "
+                               f"(K={cfg['model']['vq']['num_codebooks'][0]}), "
                                f"batch {args.batch} x {args.res}x{args.res} per GPU, bf16 ViT/head + fp32 PQ, eval forward",
                    "per_gpu_batch": args.batch, "global_batch": args.batch * world, "resolution": args.res,
                    "parallelism": f"dp{world} (images sharded, no data-path collective)"},

@@ -283,6 +283,7 @@ def main():
     manifest["histogram_case"] = {"count": cnt.tolist(), "expect": hr}
 
     probe_and_metric_fixtures(manifest, tmp)
+    bcfg_fixture(manifest, tmp)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
@@ -292,7 +293,7 @@ def main():
 
 def probe_and_metric_fixtures(manifest, tmp):
     """G9: UnSegEvaluator alone on seeded features (integer and fractional up-sampling factors, and no
-    up-sampling); G10: UnSegMetrics.  `--probes-only` regenerates just these two."""
+    up-sampling); G10: UnSegMetrics.  `--probes-only` regenerates just these two (`--bcfg-only`: G11)."""
     _stub_missing_modules()
     if REF not in sys.path:
         sys.path.insert(0, REF)
@@ -354,16 +355,44 @@ def probe_and_metric_fixtures(manifest, tmp):
     manifest["files"]["g10_metrics"] = _save("g10_metrics", **g10)
 
 
+def bcfg_fixture(manifest, tmp):
+    """G11: the ViT-B/8 + 16 x 512 PQ configuration (D = 2048) on one 64x96 image."""
+    DIONPQGO, _RefPQ, _RefCodebook, PQGOWrapper, _refq, _vits = _import_reference()
+    cfg = configs.B_CFG
+    state = synth.synth_pqgo_state(cfg, seed=1234)
+    wrapper = _ref_wrapper(cfg, state, PQGOWrapper, DIONPQGO, tmp)
+    img = synth.synth_images(1, 64, 96, seed=13)
+    code, quant, (_zs, _zq, z_index), mout = wrapper.model(img=img, aug_img=img, img_pos=None, it=-1)
+    feat = wrapper.model.extractor(img)
+    o_code, o_quant, o_index, o_mout = oracle.pqgo_forward(state, img, cfg)
+    _eq(o_code, code, "G11 code")
+    _eq(o_quant, quant, "G11 quantized")
+    _eq(o_index, z_index, "G11 indices")
+    _eq(torch.as_tensor(o_mout["vq-loss"]), torch.as_tensor(mout["vq-loss"]), "G11 vq-loss")
+    num_pq = cfg["model"]["vq"]["num_pq"][0]
+    codebooks = [state[f"model.vq_blocks.0.quantizers.{i}.embedding.weight"] for i in range(num_pq)]
+    idx64, gap64 = oracle.pq_top2_gap(codebooks, _rows(code), "l2")
+    manifest["files"]["g11_bcfg_64x96"] = _save(
+        "g11_bcfg_64x96", feat_rows=_rows(feat).numpy(), code_rows=_rows(code).numpy().astype(np.float32),
+        index=z_index.numpy().astype(np.int16), gap64=gap64.numpy().astype(np.float32),
+        fp64_agrees=np.bool_(torch.equal(idx64, z_index.reshape(num_pq, -1))), vq_loss=np.float32(mout["vq-loss"]))
+    manifest["state_dict_keys_bcfg"] = len(state)
+
+
 def probes_only():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
     with open(os.path.join(OUT, "manifest.json")) as f:
         manifest = json.load(f)
-    probe_and_metric_fixtures(manifest, tempfile.mkdtemp(prefix="equss_golden_"))
+    tmp = tempfile.mkdtemp(prefix="equss_golden_")
+    if "--probes-only" in sys.argv:
+        probe_and_metric_fixtures(manifest, tmp)
+    if "--bcfg-only" in sys.argv:
+        bcfg_fixture(manifest, tmp)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("probe / metric fixtures written to", OUT)
 
 
 if __name__ == "__main__":
-    probes_only() if "--probes-only" in sys.argv else main()
+    probes_only() if ("--probes-only" in sys.argv or "--bcfg-only" in sys.argv) else main()

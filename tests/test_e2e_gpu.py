@@ -149,3 +149,32 @@ def test_training_step_runs_and_gives_gradients(pkg, dev):
     for n, p in trainable:
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
     assert all(p.grad is None for n, p in m.named_parameters() if not p.requires_grad)
+
+
+def test_bcfg_vit_base_pq16x512(pkg, oracle, golden, dev):
+    """The ViT-B/8 configuration (C = 768, 12 heads, D = 2048, 16 x 512 codewords): every GEMM width,
+    the 12-head attention and the K = 512 PQ instance, against the reference fixture."""
+    g = golden("g11_bcfg_64x96")
+    cfg = pkg.configs.B_CFG
+    m = pkg.build_model(cfg)
+    m.load_state_dict(pkg.synth.synth_pqgo_state(cfg, seed=1234), strict=True)
+    m = m.to(dev).eval()
+    img = pkg.synth.synth_images(1, 64, 96, seed=13).to(dev)
+    with torch.no_grad():
+        code, quant, (_s, _q, z_index), outputs = m.model(img=img)
+        feat = m.model.extractor(img)
+    torch.cuda.synchronize()
+    assert code.shape == (1, 2048, 8, 12) and z_index.shape == (16, 1, 8, 12)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])   # noqa: E731
+    e_feat = _rel_l2(rows(feat).cpu().numpy(), g["feat_rows"])
+    e_code = _rel_l2(rows(code).cpu().numpy(), g["code_rows"])
+    print("G11 feature rel-L2:", e_feat, " code rel-L2:", e_code)
+    assert e_feat < FEAT_REL_L2 and e_code < CODE_REL_L2
+    # PQ on the reference's own fp32 code: exact indices
+    books = torch.stack([m.model.vq_blocks[0].quantizers[i].embedding.weight.detach() for i in range(16)])
+    idx, zq, loss = pkg.native.pq_assign(torch.from_numpy(g["code_rows"]).to(dev), books)
+    assert_index_parity(idx.cpu().numpy(), g["index"].reshape(16, -1), g["gap64"], "G11 reference code")
+    # PQ on the HIP path's own code: exact against the fp64 arg-min of that code
+    want_idx, gap = oracle.pq_top2_gap([b.cpu() for b in books], rows(code).cpu().contiguous(), "l2")
+    assert_index_parity(z_index.reshape(16, -1).cpu().numpy(), want_idx.numpy(), gap.numpy(), "G11 own code")
+    assert abs(float(outputs["vq-loss"]) - float(g["vq_loss"])) < 2e-2 * float(g["vq_loss"])
