@@ -61,6 +61,8 @@ class UnSegEvaluator(nn.Module):
             out.requires_grad or any(p.requires_grad for p in self.parameters()))
         if out.is_cuda and self.use_hip and not needs_graph:
             return self._forward_hip(out, label)
+        if out.is_cuda and self.use_hip and not out.requires_grad:
+            return self._forward_probe_grads(out, label)
         b = out.shape[0]
         step = b if (self.training and torch.is_grad_enabled()) else self.slice_images
         lin_logits, lin_preds, clu_preds, clu_inner = [], [], [], []
@@ -95,3 +97,27 @@ class UnSegEvaluator(nn.Module):
                                           self.cluster_probe.clusters.detach())
         lin, clu, losses = native.probe_eval(rows.float(), probes, bias, label.long(), b, h, w, n_lin, n_clu)
         return losses[0], lin, losses[1], clu
+
+    def _forward_probe_grads(self, out: torch.Tensor, label: torch.Tensor):
+        """The probes are being trained (gradients flow to their parameters only; the wrapper hands
+        over a detached feature map).  Same function as evaluator.py:46-82, evaluated so that autograd
+        keeps (B, classes, H, W) tensors instead of the up-sampled (B, D, H, W) map: both probes are
+        applied at low resolution and their class maps interpolated; the per-pixel feature norm, which
+        does not depend on the parameters, is computed without a graph in slices of a few images."""
+        size = label.shape[-2:]
+        same = tuple(out.shape[-2:]) == tuple(size)
+        up = (lambda t: t) if same else (lambda t: F.interpolate(t, size, mode="bilinear", align_corners=False))
+        linear_logits = up(self.linear_probe(out))
+        normed_clusters = F.normalize(self.cluster_probe.clusters, dim=1)
+        dots = up(torch.einsum("bchw,nc->bnhw", out, normed_clusters))
+        with torch.no_grad():
+            norms = torch.cat([up(out[s:s + self.slice_images]).norm(dim=1, keepdim=True)
+                               for s in range(0, out.shape[0], self.slice_images)]).clamp_min(1e-12)
+        inner = dots / norms
+        top = inner.max(dim=1)
+        cluster_loss = -top.values.mean()
+        label_flat = label.reshape(-1)
+        mask = torch.logical_and(label_flat >= 0, label_flat < self.num_classes)
+        logit_flat = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
+        linear_loss = self.linear_loss(logit_flat[mask], label_flat[mask]).mean()
+        return linear_loss, linear_logits.argmax(1), cluster_loss, top.indices
