@@ -161,6 +161,7 @@ struct ProbePixelArgs {
     const int64_t* label;
     int64_t* lin_pred;
     int64_t* clu_pred;
+    float* norm_out;         // (B, H, W) |f_up| clamped at 1e-12, or null
     float* partial;          // (blocks, 4): ce sum, valid count, max-inner sum, unused
     int B, h, w, H, W, n_lin, n_clu;
     float scale_y, scale_x;
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
             const int64_t o = ((int64_t)b * a.H + Y) * a.W + X;
             a.lin_pred[o] = best_i;
             a.clu_pred[o] = cbest_i;
+            if (a.norm_out) a.norm_out[o] = nrm;
         }
     }
     const float s_ce = equss::group_sum<64>(acc_ce);
@@ -313,8 +315,9 @@ extern "C" size_t equss_probe_workspace_bytes(int B, int h, int w, int H, int W)
 
 extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
                                 const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds,
-                                float* losses, void* workspace, size_t workspace_bytes, int B, int h, int w,
-                                int D, int H, int W, int n_linear, int n_cluster, void* stream) {
+                                float* losses, float* feature_norm, void* workspace, size_t workspace_bytes,
+                                int B, int h, int w, int D, int H, int W, int n_linear, int n_cluster,
+                                void* stream) {
     if (!feat || !probes || !bias || !label || !linear_preds || !cluster_preds || !losses || !workspace)
         return equss::fail(EQUSS_E_NULL, "equss_probe_eval: null pointer argument");
     if (B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || D <= 0 || (D % 8) != 0)
@@ -345,7 +348,7 @@ extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float*
         if (rc) return rc;
     }
     ProbePixelArgs a;
-    a.table = table; a.label = label; a.lin_pred = linear_preds; a.clu_pred = cluster_preds; a.partial = partial;
+    a.table = table; a.label = label; a.lin_pred = linear_preds; a.clu_pred = cluster_preds; a.norm_out = feature_norm; a.partial = partial;
     a.B = B; a.h = h; a.w = w; a.H = H; a.W = W; a.n_lin = n_linear; a.n_clu = n_cluster;
     a.scale_y = (float)h / (float)H;   // area_pixel_compute_scale of F.interpolate without scale_factor
     a.scale_x = (float)w / (float)W;

@@ -103,21 +103,25 @@ class UnSegEvaluator(nn.Module):
         over a detached feature map).  Same function as evaluator.py:46-82, evaluated so that autograd
         keeps (B, classes, H, W) tensors instead of the up-sampled (B, D, H, W) map: both probes are
         applied at low resolution and their class maps interpolated; the per-pixel feature norm, which
-        does not depend on the parameters, is computed without a graph in slices of a few images."""
+        does not depend on the parameters, comes from the HIP probe kernel."""
+        b, d, h, w = out.shape
         size = label.shape[-2:]
-        same = tuple(out.shape[-2:]) == tuple(size)
+        same = (h, w) == tuple(size)
         up = (lambda t: t) if same else (lambda t: F.interpolate(t, size, mode="bilinear", align_corners=False))
-        linear_logits = up(self.linear_probe(out))
-        normed_clusters = F.normalize(self.cluster_probe.clusters, dim=1)
-        dots = up(torch.einsum("bchw,nc->bnhw", out, normed_clusters))
+        lp = self.linear_probe
+        rows = out.permute(0, 2, 3, 1).reshape(b * h * w, d).float()
         with torch.no_grad():
-            norms = torch.cat([up(out[s:s + self.slice_images]).norm(dim=1, keepdim=True)
-                               for s in range(0, out.shape[0], self.slice_images)]).clamp_min(1e-12)
-        inner = dots / norms
+            probes, bias = native.pack_probes(lp.weight, lp.bias, self.cluster_probe.clusters)
+            _lin, _clu, _losses, norms = native.probe_eval(rows, probes, bias, label.long(), b, h, w, self.num_classes,
+                                                           self.cluster_probe.n_classes, want_norm=True)
+        maps = lambda t: t.reshape(b, h, w, -1).permute(0, 3, 1, 2)   # noqa: E731
+        linear_logits = up(maps(F.linear(rows, lp.weight.view(lp.out_channels, lp.in_channels), lp.bias)))
+        inner = up(maps(F.linear(rows, F.normalize(self.cluster_probe.clusters, dim=1)))) / norms.unsqueeze(1)
         top = inner.max(dim=1)
         cluster_loss = -top.values.mean()
-        label_flat = label.reshape(-1)
-        mask = torch.logical_and(label_flat >= 0, label_flat < self.num_classes)
-        logit_flat = linear_logits.permute(0, 2, 3, 1).reshape(-1, self.num_classes)
-        linear_loss = self.linear_loss(logit_flat[mask], label_flat[mask]).mean()
+        # cross-entropy over the labelled pixels (:72-80) as log-sum-exp minus the labelled logit
+        mask = torch.logical_and(label >= 0, label < self.num_classes)
+        picked = linear_logits.gather(1, label.clamp(0, self.num_classes - 1).unsqueeze(1)).squeeze(1)
+        ce = torch.logsumexp(linear_logits, dim=1) - picked
+        linear_loss = (ce * mask).sum() / mask.sum()
         return linear_loss, linear_logits.argmax(1), cluster_loss, top.indices

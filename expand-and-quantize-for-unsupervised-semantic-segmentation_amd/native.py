@@ -88,7 +88,7 @@ def _declare(lib):
     lib.equss_probe_workspace_bytes.restype = c_sz
     lib.equss_probe_workspace_bytes.argtypes = [c_int] * 5
     lib.equss_probe_eval.restype = c_int
-    lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+    lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
 
 
@@ -367,9 +367,10 @@ def pack_probes(linear_weight, linear_bias, clusters):
     return probes, bias
 
 
-def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster):
+def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster, want_norm=False):
     """feat_rows (batch*h*w, D) fp32 token-major, label (batch, H, W) int64 ->
-    (linear_preds, cluster_preds) (batch, H, W) int64 and losses (2,) fp32 = [linear CE, cluster loss]."""
+    (linear_preds, cluster_preds) (batch, H, W) int64 and losses (2,) fp32 = [linear CE, cluster loss];
+    with want_norm also the (batch, H, W) fp32 norm of the up-sampled feature per pixel."""
     _need_cuda(feat_rows, probes, bias, label)
     if feat_rows.dtype != torch.float32 or feat_rows.dim() != 2 or feat_rows.shape[0] != batch * h * w:
         raise ValueError("probe_eval: feat_rows must be (batch*h*w, D) float32")
@@ -383,11 +384,14 @@ def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster)
     lin = torch.empty((batch, H, W), dtype=torch.int64, device=dev)
     clu = torch.empty((batch, H, W), dtype=torch.int64, device=dev)
     losses = torch.empty(2, dtype=torch.float32, device=dev)
+    norm = torch.empty((batch, H, W), dtype=torch.float32, device=dev) if want_norm else None
     lib = load_library()
     nbytes = lib.equss_probe_workspace_bytes(batch, h, w, H, W)
     ws = _workspace(dev, nbytes, "probe")
     _check(lib.equss_probe_eval(_ptr(feat_rows), feat_rows.stride(0), _ptr(probes), _ptr(bias), _ptr(label),
-                                _ptr(lin), _ptr(clu), _ptr(losses), _ptr(ws), ws.numel(),
+                                _ptr(lin), _ptr(clu), _ptr(losses), _ptr(norm), _ptr(ws), ws.numel(),
                                 batch, h, w, feat_rows.shape[1], H, W, n_linear, n_cluster, _stream(feat_rows)),
            "equss_probe_eval")
+    if want_norm:
+        return lin, clu, losses, norm
     return lin, clu, losses

@@ -362,6 +362,19 @@ class DIONPQGO(nn.Module):
         self._head_key = None
 
     # -- expansion head weights for the HIP GEMMs ---------------------------------------------------
+    def _head_autograd(self, feat: torch.Tensor) -> torch.Tensor:
+        """cluster1(f) + cluster2(f) (dino_pqgo.py:104-112,:127-128) for the training pass: the 1x1
+        convolutions are per-token linears, evaluated as three GEMMs on token-major rows (the feature
+        map is a channels-first view of token-major memory, a layout convolution libraries only cover
+        with slow generic kernels)."""
+        b, c, h, w = feat.shape
+        rows = _rows_of(feat)
+        w1, w2a, w2b = self.cluster1[0], self.cluster2[0], self.cluster2[2]
+        code = F.linear(rows, w1.weight.view(w1.out_channels, c), w1.bias)
+        hid = F.relu(F.linear(rows, w2a.weight.view(w2a.out_channels, c), w2a.bias))
+        code = code + F.linear(hid, w2b.weight.view(w2b.out_channels, w2b.in_channels), w2b.bias)
+        return _nchw_of(code, b, h, w)
+
     def _head_weights(self):
         ps = [self.cluster1[0].weight, self.cluster1[0].bias, self.cluster2[0].weight, self.cluster2[0].bias,
               self.cluster2[2].weight, self.cluster2[2].bias]
@@ -403,11 +416,9 @@ class DIONPQGO(nn.Module):
 
         # training: frozen features from the HIP ViT; head and losses through autograd
         dino_feat = self.dropout(self.extractor(img))
-        code = self.cluster1(dino_feat)
-        code = code + self.cluster2(dino_feat)
+        code = self._head_autograd(dino_feat)
         dino_feat_pos = self.dropout(self.extractor(img_pos))
-        code_pos = self.cluster1(dino_feat_pos)
-        code_pos = code_pos + self.cluster2(dino_feat_pos)
+        code_pos = self._head_autograd(dino_feat_pos)
         quantized, (z_split, z_quantized, z_index), outputs, _ = self.vq_blocks[0](
             code, code_pos, it=it, return_prob=False)
         start = time.time()

@@ -222,14 +222,16 @@ int equss_expand_head(void* fh, const void* w2a, const float* b2a, const void* w
  *            cross-entropy (:72-80)
  *   linear_preds, cluster_preds (B, H, W) int64 out: first arg-max over classes (:68, :70)
  *   losses   (2) fp32 out: [0] mean cross-entropy over labelled pixels, [1] -mean max cosine (:106)
+ *   feature_norm (B, H, W) fp32 out or NULL: max(|f_up|, 1e-12) per pixel, the denominator of :96
+ *            (callers that train the probes need it to rebuild the cosine with autograd)
  *   workspace equss_probe_workspace_bytes() bytes, 256-byte aligned
  * D % 8 == 0; 1 <= n_linear, n_cluster <= 32.  All arithmetic is fp32.
  * ------------------------------------------------------------------------------------------- */
 size_t equss_probe_workspace_bytes(int B, int h, int w, int H, int W);
 int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
                      const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds, float* losses,
-                     void* workspace, size_t workspace_bytes, int B, int h, int w, int D, int H, int W,
-                     int n_linear, int n_cluster, void* stream);
+                     float* feature_norm, void* workspace, size_t workspace_bytes, int B, int h, int w, int D,
+                     int H, int W, int n_linear, int n_cluster, void* stream);
 
 #ifdef __cplusplus
 }
