@@ -24,8 +24,7 @@ namespace {
 
 constexpr int HD = 64;          // head dim
 constexpr int QW = 32;          // queries per wave
-constexpr int QB = 256;         // queries per workgroup (8 waves)
-constexpr int kAttnThreads = QB / QW * 64;
+constexpr int kPieces = 8;      // 1-KiB LDS-DMA pieces per K (or V) tile
 constexpr int KV = 64;          // keys per tile
 constexpr int kTile = KV * HD * 2;      // 8 KiB per K or V tile
 constexpr int kStage = 2 * kTile;       // K + V
@@ -47,8 +46,10 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)p);
 }
 
-template <int DIAG>
-__global__ __launch_bounds__(kAttnThreads, 4) void attention_kernel(const AttnArgs a) {
+// NW = waves per workgroup (NW * 32 queries of one (image, head)).
+template <int DIAG, int NW>
+__global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a) {
+    constexpr int QB = NW * QW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -74,24 +75,25 @@ __global__ __launch_bounds__(kAttnThreads, 4) void attention_kernel(const AttnAr
     for (int s = 0; s < 4; ++s)
         qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + 16 * s + 8 * lh);
 
-    // ---- K/V staging plan: a tile is 8 pieces of 8 rows per operand; wave w moves piece w of K and V.
-    // Source pointers are kept per lane and advanced by a scalar stride per tile; only the ragged
-    // last tile needs its row index clamped (those keys are masked in the softmax; clamping keeps
-    // the V values finite).
-    const int st_row = wave * 8 + (lane >> 3);
-    const int st_kchunk = ((lane & 7) ^ ((st_row >> 1) & 7)) * 8;
-    const int st_vchunk = ((lane & 7) ^ (((st_row >> 1) & 1) << 2)) * 8;
-    const u16* st_src = base + (size_t)st_row * ld;
+    // ---- K/V staging plan: a tile is 8 pieces of 8 rows per operand; piece p of K and of V is moved
+    // by wave p % NW (with 8 waves: one piece each).  Only the ragged last tile needs its row index
+    // clamped (those keys are masked in the softmax; clamping keeps the V values finite).
     auto stage = [&](int buf, int t) {
         char* sb = smem + buf * kStage;
-        const u16* src = st_src + (size_t)t * (KV * ld);
-        if ((t + 1) * KV > a.N) {
-            int key = t * KV + st_row;
-            if (key > a.N - 1) key = a.N - 1;
-            src = base + (size_t)key * ld;
+#pragma unroll
+        for (int p0 = 0; p0 < kPieces; p0 += NW) {
+            const int p = p0 + wave;
+            if (p < kPieces) {
+                const int st_row = p * 8 + (lane >> 3);
+                const int st_kchunk = ((lane & 7) ^ ((st_row >> 1) & 7)) * 8;
+                const int st_vchunk = ((lane & 7) ^ (((st_row >> 1) & 1) << 2)) * 8;
+                int key = t * KV + st_row;
+                if (key > a.N - 1) key = a.N - 1;
+                const u16* src = base + (size_t)key * ld;
+                glds16(src + C + st_kchunk, sb + p * 1024);
+                glds16(src + 2 * C + st_vchunk, sb + kTile + p * 1024);
+            }
         }
-        glds16(src + C + st_kchunk, sb + wave * 1024);
-        glds16(src + 2 * C + st_vchunk, sb + kTile + wave * 1024);
     };
 
     // ---- per-lane LDS read offsets -------------------------------------------------------------
@@ -244,16 +246,19 @@ int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale,
     a.qkv = reinterpret_cast<const u16*>(qkv);
     a.out = reinterpret_cast<u16*>(out);
     a.B = B; a.N = N; a.H = H;
-    a.nqb = (N + QB - 1) / QB;
+    // 256-query workgroups; short sequences use 128-query ones so fewer waves idle past the last query
+    const int nw = g_diag >= 4 && g_diag <= 8 ? g_diag : (N <= 128 ? 4 : 8);
+    const int qb = nw * QW;
+    a.nqb = (N + qb - 1) / qb;
     a.ntiles = (N + KV - 1) / KV;
     a.c = scale * 1.4426950408889634f;
     const long grid = (long)a.nqb * B * H;
     if (grid > 0x7fffffffL) return fail(EQUSS_E_SHAPE, "attention_bf16: grid too large");
-    switch (g_diag) {
-        case 1: hipLaunchKernelGGL(attention_kernel<1>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
-        case 2: hipLaunchKernelGGL(attention_kernel<2>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
-        case 3: hipLaunchKernelGGL(attention_kernel<3>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
-        default: hipLaunchKernelGGL(attention_kernel<0>, dim3((unsigned)grid), dim3(kAttnThreads), 2 * kStage, s, a); break;
+    switch (nw) {
+        case 8: hipLaunchKernelGGL((attention_kernel<0, 8>), dim3((unsigned)grid), dim3(512), 2 * kStage, s, a); break;
+        case 7: hipLaunchKernelGGL((attention_kernel<0, 7>), dim3((unsigned)grid), dim3(448), 2 * kStage, s, a); break;
+        case 6: hipLaunchKernelGGL((attention_kernel<0, 6>), dim3((unsigned)grid), dim3(384), 2 * kStage, s, a); break;
+        default: hipLaunchKernelGGL((attention_kernel<0, 4>), dim3((unsigned)grid), dim3(256), 2 * kStage, s, a); break;
     }
     return check_launch("attention_kernel");
 }

@@ -21,8 +21,6 @@
 
 namespace {
 
-constexpr int kThreads = 512;
-
 struct Gemm8Args {
     const u16* A; int64_t lda;
     const u16* W; int64_t ldw;
@@ -88,8 +86,10 @@ __device__ __forceinline__ void wait_younger(int stages, bool stores_younger) {
 }
 
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
-__global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
-    static_assert(WM * WN == 8, "eight waves");
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args g) {
+    constexpr int NW = WM * WN;                    // waves per workgroup: 8 (one workgroup per CU) or 4 (two)
+    constexpr int kThreads = NW * 64;
+    static_assert(NW == 8 || NW == 4, "four or eight waves");
     static_assert(S >= 2 && S <= 6, "ring depth");
     constexpr int TM = BM / WM, TN = BN / WN;      // per-wave output tile
     constexpr int MT = TM / 16, NT = TN / 16;      // 16 x 16 MFMA tiles per wave
@@ -97,12 +97,13 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     constexpr int CPR = BK / 8;                    // 16-byte chunks per row
     constexpr int RPP = 1024 / ROWB;               // rows per 1-KiB LDS-DMA piece
     constexpr int KS = BK / 32;                    // MFMA k sub-steps per K step
+    constexpr bool PIPE = KS == 1 && S >= 3;       // fragment reads pipelined one ring stage ahead
     constexpr int kStageBytes = (BM + BN) * ROWB;
     constexpr int A_PIECES = BM / RPP;
-    constexpr int PW = (BM + BN) / RPP / 8;        // pieces per wave per stage
+    constexpr int PW = (BM + BN) / RPP / NW;       // pieces per wave per stage
     // bf16 epilogue geometry (see the epilogue): rows per pass and 16-byte stores per lane per tile
     constexpr int ROWSTRIDE = TN * 2 + 16;
-    constexpr int RP = (kStageBytes / 8 >= 32 * ROWSTRIDE && TM >= 32) ? 32 : 16;
+    constexpr int RP = (kStageBytes / NW >= 32 * ROWSTRIDE && TM >= 32) ? 32 : 16;
     constexpr int OCH = TN * 2 / 16;
     constexpr int PER_LANE = RP * OCH / 64;
     constexpr int NST = (EPI == EQUSS_EPI_F32 || EPI == EPI_RESID_LN) ? 0 : PER_LANE * (TM / RP);
@@ -121,9 +122,6 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     const int x_len = q + (xcd < r ? 1 : 0);
     const int nslots = (gridDim.x + 7 - xcd) >> 3;
     if (slot >= x_len) return;
-    if (g.nostore >= 2 && (slot & 1)) {  // experiment: de-phase half of the CUs
-        for (int i = 0; i < g.nostore; ++i) __builtin_amdgcn_s_sleep(127);
-    }
     const int my_tiles = (x_len - slot + nslots - 1) / nslots;
     const int nk = g.K / BK;
     const int total = my_tiles * nk;
@@ -144,7 +142,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
         const int n0 = (logical % g.ntn) * BN;
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
-            const int p = i * 8 + wave;  // pieces [0, A_PIECES) are activation rows, the rest weight rows
+            const int p = i * NW + wave;  // pieces [0, A_PIECES) are activation rows, the rest weight rows
             const int row = (p < A_PIECES ? p : p - A_PIECES) * RPP + st_row;
             const int chunk = (st_phys ^ swz(row)) * 8;
             if (p < A_PIECES) {
@@ -159,8 +157,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     auto issue_one = [&]() {
         if (issued >= total) return;
         char* base = smem + i_buf * kStageBytes;
+        if (!(g.nostore & 4)) {
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(src[i] + (size_t)i_kt * BK, base + (i * 8 + wave) * 1024);
+            for (int i = 0; i < PW; ++i) glds16(src[i] + (size_t)i_kt * BK, base + (i * NW + wave) * 1024);
+        }
         ++issued;
         i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
         if (++i_kt == nk) {
@@ -190,6 +190,17 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
     // ---- compute cursor ----------------------------------------------------------------------------
     int c_tile = slot, c_buf = 0, step = 0;
     int epi_mark = 0;  // ring stages [0, epi_mark) were issued before the latest exact-count epilogue
+    typedef int frag_t __attribute__((ext_vector_type(4)));  // 8 bf16 kept as 4 dwords so copies stay whole
+    frag_t af_c[MT], wf_c[NT], af_n[MT], wf_n[NT];  // PIPE: two alternating fragment sets
+    if constexpr (PIPE) {
+        wait_younger<PW, NST>(issued - 1, false);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MT; ++i) af_c[i] = *reinterpret_cast<const frag_t*>(smem + a_base + i * 16 * ROWB + c_off[0]);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) wf_c[i] = *reinterpret_cast<const frag_t*>(smem + w_base + i * 16 * ROWB + c_off[0]);
+    }
     for (int t = 0; t < my_tiles; ++t, c_tile += nslots) {
         const int logical = x_start + c_tile;
         const int m0 = (logical / g.ntn) * BM;
@@ -218,6 +229,46 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
 #pragma unroll
                 for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (PIPE) {
+            // Software-pipelined form (BK = 32, one MFMA sub-step per ring stage): the fragments of stage
+            // step + 1 are read from LDS while the MFMAs of stage `step` run on fragments already in
+            // registers, across tile boundaries too.  Ring slot (step - 1) % S, refilled below, held the
+            // stage whose fragments every wave finished reading before it issued the MFMAs of its previous
+            // iteration, i.e. before it arrived at this barrier.
+            // One ring stage: multiply (ac, wc) while (an, wn_) is being read; the caller alternates the
+            // two register sets, so no copy is needed (nk is even: K is a multiple of 64).
+            auto stage = [&](frag_t (&ac)[MT], frag_t (&wc)[NT], frag_t (&an)[MT], frag_t (&wn_)[NT]) {
+                if (step + 1 < total) {
+                    wait_younger<PW, NST>(issued - step - 2, step + 1 < epi_mark);
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    issue_one();
+                }
+                // (after the very last stage this reads a slot nobody uses again; the values are dropped)
+                const int nb = c_buf + 1 == S ? 0 : c_buf + 1;
+                const char* base = smem + nb * kStageBytes;
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    an[i] = *reinterpret_cast<const frag_t*>(base + a_base + i * 16 * ROWB + c_off[0]);
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+                    wn_[i] = *reinterpret_cast<const frag_t*>(base + w_base + i * 16 * ROWB + c_off[0]);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wc[nt]),
+                                                                              __builtin_bit_cast(bf16x8, ac[mt]),
+                                                                              acc[nt][mt], 0, 0, 0);
+                asm volatile("" ::: "memory");
+                c_buf = c_buf + 1 == S ? 0 : c_buf + 1;
+                ++step;
+            };
+            for (int kt = 0; kt < nk; kt += 2) {
+                stage(af_c, wf_c, af_n, wf_n);
+                stage(af_n, wf_n, af_c, wf_c);
+            }
+        } else {
         for (int kt = 0; kt < nk; ++kt, ++step) {
             // this wave's pieces of stage `step` have landed once at most (issued - step - 1) younger
             // stages are outstanding (operations retire in order; epilogue stores in the queue only make
@@ -231,12 +282,19 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 af[MT], wf[NT];
+                if (g.nostore & 2) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) { af[i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(af[i])); }
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) { wf[i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(wf[i])); }
+                } else {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     af[i] = *reinterpret_cast<const bf16x8*>(base + a_base + i * 16 * ROWB + c_off[ks]);
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
                     wf[i] = *reinterpret_cast<const bf16x8*>(base + w_base + i * 16 * ROWB + c_off[ks]);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -245,6 +303,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
             }
             asm volatile("" ::: "memory");
             c_buf = c_buf + 1 == S ? 0 : c_buf + 1;
+        }
         }
         // ---- epilogue (stores only) ---------------------------------------------------------------------
         if constexpr (EPI == EPI_RESID_LN) {
@@ -273,7 +332,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
             }
             if (g.ln) {
                 const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
-                char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / 8);
+                char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / NW);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();  // partial sums visible; ring slot no longer read
                 asm volatile("" ::: "memory");
@@ -335,10 +394,10 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
             static_assert(RP * OCH % 64 == 0, "epilogue chunking");
             // A full tile issues exactly NST stores per wave, which lets the waits that follow leave them
             // in flight; the ragged last row-tile masks stores, so it falls back to the stricter wait.
-            const bool full = m0 + BM <= g.M && g.nostore != 1;
+            const bool full = m0 + BM <= g.M && !(g.nostore & 1);
             epi_mark = full ? issued : 0;
             const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
-            char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / 8);
+            char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / NW);
             __builtin_amdgcn_s_barrier();  // every wave is done reading that slot
             asm volatile("" ::: "memory");
 #pragma unroll
@@ -370,7 +429,7 @@ __global__ __launch_bounds__(kThreads, 2) void gemm8_kernel(const Gemm8Args g) {
                     const int row = idx / OCH, ch = idx % OCH;
                     const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                     const int m = m0 + wm * TM + pass * RP + row;
-                    if (g.nostore == 1) { asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); continue; }
+                    if (g.nostore & 1) { asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); continue; }
                     if (full || m < g.M)
                         *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n0 + wn * TN + ch * 8) = d;
                 }
@@ -387,7 +446,9 @@ int g_nostore = 0;
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
 int launch_inst(const Gemm8Args& g, hipStream_t s) {
     const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
-    const int grid = ntiles < 256 ? ntiles : 256;  // one resident workgroup per CU
+    constexpr int kThreads = WM * WN * 64;
+    constexpr int resident = WM * WN == 8 ? 256 : 512;  // one 8-wave or two 4-wave workgroups per CU
+    const int grid = ntiles < resident ? ntiles : resident;
     constexpr int ring = S * (BM + BN) * BK * 2;
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
     constexpr int extra = EPI == EPI_RESID_LN ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
@@ -416,8 +477,16 @@ int launch_shape(const Gemm8Args& g, hipStream_t s) {
 
 template <int EPI>
 int launch(Gemm8Args& g, hipStream_t s) {
+    if (g_stages == 5 && g.N % 384 == 0) {
+        g.ntn = g.N / 384;
+        return launch_inst<EPI, 128, 384, 1, 4, 32, 2>(g, s);
+    }
     if (g.N % 384 == 0 && !(g_prefer256 && g.N % 256 == 0)) {
         g.ntn = g.N / 384;
+        // short-K, store-heavy shapes (qkv) run a little faster on the 4-deep ring of 32-wide stages
+        // with fragment reads pipelined one stage ahead
+        if (EPI == EQUSS_EPI_BF16 && g.K <= 512 && g.N > 384 && g_stages == 2)
+            return launch_inst<EPI, 128, 384, 2, 4, 32, 4>(g, s);
         return launch_shape<EPI, 128, 384, 2, 4>(g, s);
     }
     g.ntn = g.N / 256;
@@ -460,6 +529,7 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
     g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1; g.nostore = 0;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
+    if (g_stages == 5) return launch_inst<EPI_RESID_LN, 128, 384, 1, 4, 32, 2>(g, s);
     return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);
 }
 

@@ -174,6 +174,28 @@ int layernorm(const float* x, int64_t ld_x, const float* gamma, const float* bet
     return equss::check_launch("layernorm_kernel");
 }
 
+// x += A W^T + bias, ln = LayerNorm(x), with the workgroup count balanced against the chip.
+// The fused kernel walks 128-row tiles with one persistent workgroup per CU, so a tile count just
+// above a multiple of 256 leaves most CUs idle for a whole extra round (64 x 1601 tokens = 801 tiles
+// = 3 rounds + 33 tiles).  Those trailing rows go through the 128 x 128-tile residual GEMM (three times
+// as many, smaller tiles, two workgroups per CU) and a LayerNorm launch of their own instead.
+int resid_ln_balanced(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
+                      const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, int N, int K, float eps,
+                      hipStream_t s) {
+    const int tiles = (M + 127) / 128, rounds = tiles / 256, rem = tiles % 256;
+    if (rounds < 1 || rem == 0 || rem > 128)
+        return equss::gemm8_resid_ln(A, lda, W, ldw, bias, x, ldx, gamma, beta, ln, ld_ln, M, N, K, eps, s);
+    const int m_main = rounds * 256 * 128, m_tail = M - m_main;
+    int rc = equss::gemm8_resid_ln(A, lda, W, ldw, bias, x, ldx, gamma, beta, ln, ld_ln, m_main, N, K, eps, s);
+    if (rc) return rc;
+    const u16* a_tail = reinterpret_cast<const u16*>(A) + (size_t)m_main * lda;
+    float* x_tail = x + (size_t)m_main * ldx;
+    rc = equss::gemm_bf16(a_tail, lda, W, ldw, bias, x_tail, ldx, m_tail, N, K, EQUSS_EPI_RESID_F32, s);
+    if (rc || !ln) return rc;
+    return layernorm(x_tail, ldx, gamma, beta, reinterpret_cast<u16*>(ln) + (size_t)m_main * ld_ln, ld_ln, nullptr, m_tail,
+                     N, 0, eps, s);
+}
+
 int patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls, const float* pos,
                  float* x, void* ws, int B, int H, int W, int P, int C, hipStream_t s) {
     PatchWs w = carve_patch(ws, B, H, W, P, C);
@@ -278,7 +300,7 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         EQUSS_STEP(EQUSS_K_GEMM_QKV, equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))
         EQUSS_STEP(EQUSS_K_ATTENTION, equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))
         if (fuse) {
-            EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm8_resid_ln(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
+            EQUSS_STEP(EQUSS_K_GEMM_PROJ, resid_ln_balanced(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
         } else {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))
             EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
@@ -286,7 +308,7 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         EQUSS_STEP(EQUSS_K_GEMM_FC1, equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))
         if (fuse) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
-            EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm8_resid_ln(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, C, rows, C, 4 * C, 1e-6f, s))
+            EQUSS_STEP(EQUSS_K_GEMM_FC2, resid_ln_balanced(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, C, rows, C, 4 * C, 1e-6f, s))
         } else {
             EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))
         }
@@ -305,8 +327,8 @@ extern "C" int equss_gemm_resid_ln_bf16(const void* A, int64_t lda, const void* 
     if (lda < K || ldw < K || ldx < N || (ln_out && ld_ln < N) || (lda % 8) || (ldw % 8) || (ldx % 4) || (ld_ln % 8) ||
         ((uintptr_t)A % 16) || ((uintptr_t)W % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
         return equss::fail(EQUSS_E_ALIGN, "gemm_resid_ln: operands must be 16-byte aligned with padded leading dimensions");
-    return equss::gemm8_resid_ln(A, lda, W, ldw, bias, x, ldx, gamma, beta, ln_out, ld_ln, M, N, K, eps,
-                                 reinterpret_cast<hipStream_t>(stream));
+    return resid_ln_balanced(A, lda, W, ldw, bias, x, ldx, gamma, beta, ln_out, ld_ln, M, N, K, eps,
+                             reinterpret_cast<hipStream_t>(stream));
 }
 
 // code = [f | relu(f W2a^T + b2a)] [W1 | W2b]^T + (b1 + b2b)   (model/dino_pqgo.py:104-112,:127-128)

@@ -18,6 +18,10 @@ import ctypes
 for diag in [int(a) for a in sys.argv[1:]] or [0]:
     nat.load_library().equss_dev_attn_diag(ctypes.c_int(diag))
     out = nat.attention_bf16(qkv, B, N, H, 0.125)
+    if diag == 8 or diag == 0:
+        ref = out.float().clone()
+    else:
+        print("   max |diff| vs 8 waves:", float((out.float() - ref).abs().max()))
     e0.record()
     for _ in range(10):
         out = nat.attention_bf16(qkv, B, N, H, 0.125)
