@@ -218,7 +218,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = m0 + wm * TM + mt * 16 + fr;
                     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
+                    if (m < g.M && !(g.nostore & 8)) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
                     o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
                     acc[nt][mt] = o;
                 }
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = wn * TN + nt * 16 + fq * 4;
                     const f32x4 v = acc[nt][mt];
-                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+                    if (m < g.M && !(g.nostore & 1)) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
                     s1[mt] += (v.x + v.y) + (v.z + v.w);
                     s2[mt] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         const int row = idx / OCH, ch = idx % OCH;
                         const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                         const int m = m0 + wm * TM + pass * RP + row;
-                        if (m < g.M) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * TN + ch * 8) = d;
+                        if (m < g.M && !(g.nostore & 16)) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * TN + ch * 8) = d;
                     }
                     asm volatile("" ::: "memory");
                 }
@@ -527,7 +527,7 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
     Gemm8Args g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
-    g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1; g.nostore = 0;
+    g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1; g.nostore = g_nostore;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
     if (g_stages == 5) return launch_inst<EPI_RESID_LN, 128, 384, 1, 4, 32, 2>(g, s);
     return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);

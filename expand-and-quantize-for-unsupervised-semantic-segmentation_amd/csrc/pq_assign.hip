@@ -237,6 +237,283 @@ __global__ __launch_bounds__(kPqThreads, 2) void pq_assign_kernel(const PqArgs a
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Screened search (l2 normalisation, d = 128, K * d * 2 <= 64 KiB): the exact fp32 search above
+// spends 2 K flop per 8 bytes of row traffic and is bound by the fp32 matrix rate, not by HBM.
+// Here an fp16 MFMA pass scores every codeword with a proven error bound, and only codewords whose
+// fp16 score is within that bound of the best one are re-scored in exact fp32 -- on typical data
+// 1.1 per row, so the kernel streams rows near memory speed while returning the same index as the
+// exact search.
+//
+// Bound.  After l2 normalisation |zn_i|, |cn_i| <= 1, so fp16 (11 significant bits, round to
+// nearest) carries each with relative error <= 2^-11, or absolute error <= 2^-25 below the fp16
+// normal range.  Products are exact in fp32; the fp32 accumulation over d = 128 terms adds at most
+// 2^-17 relative.  Hence |<zn,cn>_fp16 - <zn,cn>| <= e |zn| |cn| + 1e-6 with e = 2^-10 + 2^-16
+// (Cauchy-Schwarz on sum |zn_i| |cn_i|).  Maximising v_k = <zn,cn_k> - csq_k / 2 is minimising the
+// distance; the exact maximiser k* has v~_k* >= max v~ - 2 e |zn| max|cn| - 2e-6, so every k with
+// v~_k >= max v~ - T is kept, T = 2 e |zn| max|cn| + 2e-6 plus a margin of 1e-5 (|zn|^2 + max|cn|^2) / 2
+// for the fp32 rounding of the exact evaluation.  Whatever is dropped loses by more than that margin
+// in exact arithmetic.
+//
+// Each wave works alone on 16-row tiles (no workgroup barrier in the loop): rows HBM -> registers
+// (next tile prefetched) -> normalise -> fp16 B fragments through a private 4 KiB LDS tile; the fp16
+// codebook of the sub-space sits in LDS (A operand, conflict-free ds_read_b128); pass 1 finds the
+// best score per row, pass 2 recomputes the scores into a per-lane bit mask of survivors (branch
+// free); a single survivor is the answer, several are listed per row and scored in exact fp32 by a
+// half-wave each, straight from the row registers.
+// ---------------------------------------------------------------------------------------------
+// Sum over the 32 lanes that hold one row: four DPP adds (quad swaps, half-row and row mirrors)
+// cover 16 lanes without touching the LDS crossbar, one shuffle joins the two 16-lane rows.
+__device__ __forceinline__ float row32_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+    return x + __shfl_xor(x, 16, 64);
+}
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// two fp32 -> one dword of two fp16, round to nearest even
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+    typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+    const f16x2 v = {(_Float16)lo, (_Float16)hi};
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+constexpr int kScrCap = 8;      // survivors listed per row; more -> exact scan of all K for that row
+constexpr float kScrE = 0.0009765625f + 0.0000152587890625f;  // 2^-10 + 2^-16
+constexpr int kScrThreads = 768;    // 12 independent waves per workgroup (three per SIMD, <= 168 VGPRs)
+constexpr int kScrRows = 16;        // rows per wave tile (v_mfma_f32_16x16x32_f16)
+constexpr int kScrWaveLds = kScrRows * 256 + kScrRows * 4 * 2 + kScrRows * kScrCap * 4;
+
+template <int D>
+__global__ __launch_bounds__(kScrThreads, 3) void pq_screen_kernel(const PqArgs a) {
+    static_assert(D == 128, "fragment and swizzle arithmetic below is written for d = 128");
+    constexpr int LPR = D / 4;            // lanes holding one row as float4 each
+    constexpr int RPI = 64 / LPR;         // rows per wave-wide load
+    constexpr int NI = kScrRows / RPI;    // float4 per lane per tile
+    constexpr int KB = D / 32;            // MFMA k blocks
+    constexpr int ROWB = D * 2;           // bytes per fp16 row
+    constexpr int NWAVES = kScrThreads / 64;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = a.K, p = blockIdx.y;
+    const int j = lane & 15, q = lane >> 4;
+
+    char* cb_s = smem;                                              // K x D fp16, chunk-swizzled
+    float* csq_s = reinterpret_cast<float*>(cb_s + (size_t)K * ROWB);  // K
+    float* red_s = csq_s + K;                                       // 16
+    char* wbase = reinterpret_cast<char*>(red_s + 16) + wave * kScrWaveLds;
+    char* zb = wbase;                                               // 16 x D fp16, chunk-swizzled
+    int* cnt_s = reinterpret_cast<int*>(zb + kScrRows * ROWB);      // 16
+    int* fin_s = cnt_s + kScrRows;                                  // 16
+    int* cand_s = fin_s + kScrRows;                                 // 16 x kScrCap
+
+    // ---- codebook -> LDS as fp16; max |cn|^2 ----------------------------------------------------
+    float cmax2 = 0.f;
+    for (int item = tid; item < K * LPR; item += kScrThreads) {
+        const int row = item / LPR, c = item % LPR;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.cn + ((size_t)p * K + row) * D + 4 * c);
+        uint2 pk;
+        pk.x = pack_f16(v.x, v.y);
+        pk.y = pack_f16(v.z, v.w);
+        *reinterpret_cast<uint2*>(cb_s + row * ROWB + (((c >> 1) ^ (row & 15)) * 16) + (c & 1) * 8) = pk;
+    }
+    for (int k = tid; k < K; k += kScrThreads) {
+        const float sq = a.csq[(size_t)p * K + k];
+        csq_s[k] = sq;
+        cmax2 = fmaxf(cmax2, sq);
+    }
+    cmax2 = equss::group_max<64>(cmax2);
+    if (lane == 0) red_s[wave] = cmax2;
+    __syncthreads();
+    cmax2 = red_s[0];
+#pragma unroll
+    for (int w = 1; w < NWAVES; ++w) cmax2 = fmaxf(cmax2, red_s[w]);
+    __syncthreads();   // red_s is reused for the loss at the end
+
+    const int wave_g = blockIdx.x * NWAVES + wave;
+    const int nwaves = gridDim.x * NWAVES;
+    const int rsub = lane / LPR, c4 = lane % LPR;   // this lane's row within a load and its float4 column
+    float loss = 0.f;
+
+    // Loads are unconditional: rows past the end re-read the last row (their outputs are never stored).
+    f32x4 pre[NI];
+    const float* code_p = a.code + (size_t)p * D + 4 * c4;
+    auto fetch = [&](int tile) {
+        const int t = min(tile, a.ntiles - 1);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int grow = min(t * kScrRows + i * RPI + rsub, a.rows - 1);
+            pre[i] = *reinterpret_cast<const f32x4*>(code_p + (size_t)grow * a.ld_code);
+        }
+    };
+    fetch(wave_g);
+
+    for (int tile = wave_g; tile < a.ntiles; tile += nwaves) {
+        // ---- normalise; fp16 copy -> private LDS tile ----------------------------------------------
+        f32x4 cur[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            // F.normalize(dim=1, eps=1e-12): x / max(||x||, eps)
+            f32x4 v = pre[i];
+            const float den = fmaxf(sqrtf(row32_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w)), 1e-12f);
+            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            cur[i] = v;
+            const int r = i * RPI + rsub;
+            uint2 pk;
+            pk.x = pack_f16(v.x, v.y);
+            pk.y = pack_f16(v.z, v.w);
+            *reinterpret_cast<uint2*>(zb + r * ROWB + (((c4 >> 1) ^ (r & 15)) * 16) + (c4 & 1) * 8) = pk;
+        }
+        if (lane < kScrRows) cnt_s[lane] = 0;
+        fetch(tile + nwaves);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS writes are visible to its reads
+        // B fragments: lane (j, q) holds zn[j][32 t + 8 q .. + 7]
+        f16x8 bf[KB];
+#pragma unroll
+        for (int t = 0; t < KB; ++t)
+            bf[t] = *reinterpret_cast<const f16x8*>(zb + j * ROWB + (((4 * t + q) ^ j) * 16));
+
+        // scores of codeword tile ct: lane (j, q) gets v~ = <zn_j, cn_k> - csq_k / 2 for k = 16 ct + 4 q + e in acc[e]
+        auto scores = [&](int ct) {
+            const f32x4 sq = *reinterpret_cast<const f32x4*>(csq_s + ct * 16 + 4 * q);
+            f32x4 acc = {-0.5f * sq.x, -0.5f * sq.y, -0.5f * sq.z, -0.5f * sq.w};
+            const char* arow = cb_s + (ct * 16 + j) * ROWB;
+#pragma unroll
+            for (int t = 0; t < KB; ++t) {
+                const f16x8 af = *reinterpret_cast<const f16x8*>(arow + (((4 * t + q) ^ j) * 16));
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(af, bf[t], acc, 0, 0, 0);
+            }
+            return acc;
+        };
+
+        // ---- pass 1: best and second-best score per row ------------------------------------------------
+        float best = -__builtin_inff();
+        const int diag = a.WK;
+        for (int ct = 0; ct < ((diag & 2) ? 0 : K / 16); ct += 2) {
+            const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
+            best = fmaxf(fmaxf(best, fmaxf(a0.x, a0.y)), fmaxf(a0.z, a0.w));
+            best = fmaxf(fmaxf(best, fmaxf(a1.x, a1.y)), fmaxf(a1.z, a1.w));
+        }
+        best = fmaxf(best, __shfl_xor(best, 16, 64));   // the four lanes that share a row
+        best = fmaxf(best, __shfl_xor(best, 32, 64));
+        // |zn| <= 1 (+ rounding) after l2 normalisation, whatever the row held
+        constexpr float zs = 1.0001f;
+        const float T = 2.0f * kScrE * sqrtf(zs * cmax2) + 0.5e-5f * (zs + cmax2) + 2e-6f;
+        const float thr = best - T;   // (NaN scores compare false everywhere: the row ends with index 0)
+
+        // ---- pass 2: recompute the scores; one bit per (codeword of this lane) that survives --------------
+        // Branch-free: mask = 2 mask + (score >= thr), two 32-bit words for up to 64 codewords per lane
+        // (K <= 256).  Value n of a word (n = 4 (ct - ct0) + e) ends at bit nv - 1 - n.
+        const int nct = K / 16;
+        uint32_t mk[2] = {0u, 0u};
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int ct_end = min(nct, 8 * w + 8);
+            for (int ct = 8 * w; ct < ((diag & 1) ? 0 : ct_end); ct += 2) {
+                const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mk[w] = (mk[w] << 1) | (a0[e] >= thr ? 1u : 0u);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) mk[w] = (mk[w] << 1) | (a1[e] >= thr ? 1u : 0u);
+            }
+        }
+        const int nv0 = 4 * min(nct, 8), nv1 = 4 * max(nct - 8, 0);
+        auto codeword = [&](int w, int bit) {   // bit of word w -> codeword index
+            const int n = (w == 0 ? nv0 : nv1) - 1 - bit;
+            return 16 * (8 * w + (n >> 2)) + 4 * q + (n & 3);
+        };
+        const int mine = __popc(mk[0]) + __popc(mk[1]);
+        int total = mine + __shfl_xor(mine, 16, 64);
+        total += __shfl_xor(total, 32, 64);
+        int hit = -1;
+        if (mine == 1) hit = mk[0] ? codeword(0, 31 - __clz(mk[0])) : codeword(1, 31 - __clz(mk[1]));
+        hit = max(hit, __shfl_xor(hit, 16, 64));
+        hit = max(hit, __shfl_xor(hit, 32, 64));
+        if (lane < kScrRows) fin_s[lane] = max(hit, 0);   // right when exactly one codeword survived
+        if (total >= 2 && mine > 0 && !(diag & 8)) {       // several survivors: list them for the exact pass
+#pragma unroll
+            for (int w = 0; w < 2; ++w) {
+                uint32_t m = mk[w];
+                while (m) {
+                    const int bit = 31 - __clz(m);
+                    m &= ~(1u << bit);
+                    const int slot = atomicAdd(&cnt_s[j], 1);
+                    if (slot < kScrCap) cand_s[j * kScrCap + slot] = codeword(w, bit);
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+        // ---- exact fp32 re-scoring of rows with several survivors: a half-wave per row ---------------
+        // dist = (|zn|^2 + |cn|^2) - 2 <zn, cn>, smaller distance wins, then smaller index.
+        if (__builtin_amdgcn_ballot_w64(total >= 2) != 0 && !(diag & 16)) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int r = i * RPI + rsub;
+                const int n = tile * kScrRows + r < a.rows ? cnt_s[r] : 0;   // padding rows of the last tile are skipped
+                if (n >= 2) {
+                    const f32x4 z = cur[i];
+                    const float zq = row32_sum(z.x * z.x + z.y * z.y + z.z * z.z + z.w * z.w);
+                    const int count = n > kScrCap ? K : n;   // list overflowed: exact scan of the whole codebook
+                    float bd = __builtin_inff();
+                    int bk = 0;
+                    for (int ci = 0; ci < count; ci += 2) {   // two candidates per step: their loads overlap
+                        const int cj = ci + 1 < count ? ci + 1 : ci;
+                        const int k0 = n > kScrCap ? ci : cand_s[r * kScrCap + ci];
+                        const int k1 = n > kScrCap ? cj : cand_s[r * kScrCap + cj];
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.cn + ((size_t)p * K + k0) * D + 4 * c4);
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.cn + ((size_t)p * K + k1) * D + 4 * c4);
+                        const float dot0 = row32_sum(fmaf(z.x, c0.x, fmaf(z.y, c0.y, fmaf(z.z, c0.z, z.w * c0.w))));
+                        const float dot1 = row32_sum(fmaf(z.x, c1.x, fmaf(z.y, c1.y, fmaf(z.z, c1.z, z.w * c1.w))));
+                        const float d0 = (zq + csq_s[k0]) - 2.0f * dot0;
+                        const float d1 = (zq + csq_s[k1]) - 2.0f * dot1;
+                        if (d0 < bd || (d0 == bd && k0 < bk)) { bd = d0; bk = k0; }
+                        if (d1 < bd || (d1 == bd && k1 < bk)) { bd = d1; bk = k1; }
+                    }
+                    if (c4 == 0) fin_s[r] = bk;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane < kScrRows && tile * kScrRows + lane < a.rows)
+            a.idx[(size_t)p * a.rows + tile * kScrRows + lane] = (int64_t)fin_s[lane];
+
+        // ---- gather + straight-through output + mse numerator, from the row registers -----------------
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = i * RPI + rsub;
+            const int grow = tile * kScrRows + r;
+            if (grow < a.rows) {
+                const int k = fin_s[r];
+                const f32x4 zn = cur[i];
+                const f32x4 e = *reinterpret_cast<const f32x4*>(a.gather + ((size_t)p * K + k) * D + 4 * c4);
+                f32x4 df; df.x = e.x - zn.x; df.y = e.y - zn.y; df.z = e.z - zn.z; df.w = e.w - zn.w;
+                loss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+                if (a.zq && !(diag & 4)) {
+                    f32x4 o; o.x = zn.x + df.x; o.y = zn.y + df.y; o.z = zn.z + df.z; o.w = zn.w + df.w;
+                    *reinterpret_cast<f32x4*>(a.zq + (size_t)grow * a.ld_zq + (size_t)p * D + 4 * c4) = o;
+                }
+            }
+            if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two gathers in flight, not all eight
+        }
+        asm volatile("" ::: "memory");
+    }
+    // ---- per-workgroup loss partial (fixed order, no atomics) ----------------------------------
+    loss = group_sum<64>(loss);
+    if (lane == 0) red_s[wave] = loss;
+    __syncthreads();
+    if (tid == 0) {
+        float s = 0.f;
+        for (int w = 0; w < NWAVES; ++w) s += red_s[w];
+        a.loss_partial[(size_t)p * kMaxGridX + blockIdx.x] = s;
+    }
+}
+
 __global__ void pq_loss_reduce(const float* __restrict__ partial, float* __restrict__ loss_sum, int gx) {
     const int p = blockIdx.x;
     if (threadIdx.x == 0) {
@@ -323,6 +600,8 @@ bool make_plan(int K, int d, PqPlan* pl) {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+int g_pq_mode = 0;  // 0: screened search where it applies; 1: exact fp32 search everywhere
+
 struct PqWorkspace { float* cn; float* csq; float* loss_partial; size_t bytes; };
 
 PqWorkspace carve(void* ws, int num_pq, int K, int d) {
@@ -404,6 +683,8 @@ int check_common(const float* code, int64_t ld_code, const float* codebooks, voi
 
 }  // namespace
 
+extern "C" void equss_dev_pq_mode(int m) { g_pq_mode = m; }  // test knob, not part of the ABI
+
 extern "C" size_t equss_pq_workspace_bytes(int rows, int num_pq, int K, int d) {
     (void)rows;
     if (num_pq <= 0 || K <= 0 || d <= 0) return 0;
@@ -440,6 +721,33 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
     a.WK = pl.WK; a.WR = pl.WR; a.RT = pl.RT;
     a.ntiles = (rows + pl.R - 1) / pl.R;
     int gx = (256 + num_pq - 1) / num_pq;  // one resident workgroup per CU
+    const bool screened = (g_pq_mode & 15) != 1 && d == 128 && normalize == EQUSS_NORM_L2 && (size_t)K * d * 2 <= 65536;  // (K % 32 == 0 already checked)
+    if (screened) {
+        a.ntiles = (rows + kScrRows - 1) / kScrRows;
+        a.WK = g_pq_mode >> 4;  // developer timing switches (0 in normal use)
+        const int waves = kScrThreads / 64;
+        if (gx > (a.ntiles + waves - 1) / waves) gx = (a.ntiles + waves - 1) / waves;
+        if (gx > kMaxGridX) gx = kMaxGridX;
+        const size_t lds = (size_t)K * d * 2 + (K + 16) * 4 + (size_t)waves * kScrWaveLds;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(pq_screen_kernel<128>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
+                return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve LDS for the screened search");
+            attr_done = true;
+        }
+        {
+            equss::ProfScope ps(EQUSS_K_PQ_ASSIGN, s);
+            hipLaunchKernelGGL(pq_screen_kernel<128>, dim3(gx, num_pq), dim3(kScrThreads), lds, s, a);
+            rc = equss::check_launch("pq_screen_kernel");
+        }
+        if (rc) return rc;
+        if (loss_sum) {
+            hipLaunchKernelGGL(pq_loss_reduce, dim3(num_pq), dim3(64), 0, s, w.loss_partial, loss_sum, gx);
+            rc = equss::check_launch("pq_loss_reduce");
+        }
+        return rc;
+    }
     if (gx > a.ntiles) gx = a.ntiles;
     if (gx > kMaxGridX) gx = kMaxGridX;
     if (gx < 1) gx = 1;

@@ -84,3 +84,60 @@ def test_pq_assign_rejects_bad_shapes(native, dev):
         native.pq_assign(torch.zeros(8, 64, device=dev), torch.zeros(1, 32, 64, device=dev), "bogus")
     idx, zq, loss = native.pq_assign(torch.zeros(0, 64, device=dev), torch.zeros(1, 32, 64, device=dev), "l2")
     assert idx.shape == (1, 0) and zq.shape == (0, 64)
+
+
+# ---- the screened search (fp16 MFMA scores + exact fp32 re-scoring of the survivors) -------------------
+def _force_exact(native, on):
+    import ctypes
+    native.load_library().equss_dev_pq_mode(ctypes.c_int(1 if on else 0))
+
+
+def _check_against_fp64(idx, want, gap, what, tol=2e-6):
+    got = idx.cpu().numpy()
+    bad = (got != want.numpy()) & (gap.numpy() > tol)
+    assert not bad.any(), f"{what}: {int(bad.sum())} mismatches outside near-ties"
+
+
+def _adversarial_case(kind, rows, k, seed):
+    g = np.random.Generator(np.random.PCG64(seed))
+    d, num_pq = 128, 2
+    code = g.standard_normal((rows, num_pq * d)).astype(np.float32)
+    books = g.uniform(-1, 1, size=(num_pq, k, d)).astype(np.float32)
+    if kind == "clustered":       # codewords in tight clusters: many survivors per row, lists overflow
+        centres = g.standard_normal((num_pq, 4, d)).astype(np.float32)
+        books = centres[:, g.integers(0, 4, size=k)] + 1e-3 * g.standard_normal((num_pq, k, d)).astype(np.float32)
+    elif kind == "duplicates":    # exact duplicate codewords: exact ties, the lower index must win
+        books[:, k // 2:] = books[:, : k - k // 2]
+    elif kind == "on_codeword":   # rows that ARE codewords (distance 0 up to rounding), zero and tiny rows
+        for p in range(num_pq):
+            pick = g.integers(0, k, size=rows)
+            code[:, p * d:(p + 1) * d] = 3.0 * books[p, pick]
+        code[::7] = 0.0
+        code[3::11] *= 1e-20
+    return torch.from_numpy(code), torch.from_numpy(books)
+
+
+@pytest.mark.parametrize("kind,rows,k", [("random", 1000, 256), ("random", 333, 128), ("random", 777, 64),
+                                         ("clustered", 600, 256), ("duplicates", 500, 128),
+                                         ("on_codeword", 900, 256)])
+def test_screened_search_equals_exact_search(kind, rows, k, native, oracle, dev):
+    code, books = _adversarial_case(kind, rows, k, seed=rows + k)
+    want, gap = oracle.pq_top2_gap([b for b in books], code, "l2")
+    try:
+        _force_exact(native, True)
+        idx_e, zq_e, loss_e = native.pq_assign(code.to(dev), books.to(dev))
+        _force_exact(native, False)
+        idx_s, zq_s, loss_s = native.pq_assign(code.to(dev), books.to(dev))
+    finally:
+        _force_exact(native, False)
+    torch.cuda.synchronize()
+    _check_against_fp64(idx_e, want, gap, kind + " exact kernel")
+    _check_against_fp64(idx_s, want, gap, kind + " screened kernel")
+    if kind == "duplicates":      # ties between identical codewords resolve to the first one in both kernels
+        assert int(idx_s.max()) < k - k // 2 + (k % 2) and torch.equal(idx_s, idx_e)
+    same = (idx_s == idx_e).all(dim=0).cpu().numpy()
+    np.testing.assert_allclose(zq_s.cpu().numpy()[same], zq_e.cpu().numpy()[same], rtol=0, atol=1e-6)
+    assert torch.allclose(loss_s, loss_e, rtol=1e-4)
+    # the screened kernel is deterministic run to run, loss included
+    idx_2, zq_2, loss_2 = native.pq_assign(code.to(dev), books.to(dev))
+    assert torch.equal(idx_2, idx_s) and torch.equal(zq_2, zq_s) and torch.equal(loss_2, loss_s)

@@ -29,9 +29,13 @@ for diag in [int(a) for a in sys.argv[1:]] or [0]:
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"attention diag {diag}: {us:.1f} us  {4.0 * B * N * N * 384 / us / 1e6:.1f} TF")
 nat.load_library().equss_dev_attn_diag(ctypes.c_int(0))
-e0.record()
-for _ in range(10):
+for mode in (0, 1, 256, 128, 16):
+    nat.load_library().equss_dev_pq_mode(ctypes.c_int(mode))
     nat.pq_assign(code, books, "l2")
-e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 10 * 1e3
-print(f"pq_assign {us:.1f} us  {2.0 * B * 1600 * 1024 * 256 / us / 1e6:.1f} TF fp32  {B * 1600 * (8192 + 64) / us / 1e3:.1f} GB/s")
+    e0.record()
+    for _ in range(10):
+        nat.pq_assign(code, books, "l2")
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    print(f"pq_assign mode {mode}: {us:.1f} us  {2.0 * B * 1600 * 1024 * 256 / us / 1e6:.1f} TF fp32  {B * 1600 * (8192 + 64) / us / 1e3:.1f} GB/s")
+nat.load_library().equss_dev_pq_mode(ctypes.c_int(0))
