@@ -14,7 +14,8 @@
 //    scores: the row max / row sum are in-lane scans plus one cross-half shuffle.
 //  * The S^T accumulators, exponentiated and packed to bf16, are already the B operand of
 //    O^T = V^T P^T (rows of S^T are the summed index), so P never touches LDS.
-//  * Online softmax in fp32 (exp2 with the scale folded in); O is rescaled per tile.
+//  * Online softmax in fp32 (exp2 with the scale folded in); O is rescaled only when the running
+//    maximum has grown by more than 8 in the exponent.
 //  * Workgroup ids are remapped so the query blocks of one (image, head) run on one XCD and share
 //    its K/V in that XCD's L2.
 #include "equss_common.h"
@@ -70,10 +71,24 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
     const bool q_valid = qrow < a.N;
     const bool wave_active = qb * QB + wave * QW < a.N;  // waves past the last query only help staging
     if (!q_valid) qrow = a.N - 1;
+    // q is pre-multiplied by scale * log2(e), so the MFMA result is already the exponent of exp2.
     bf16x8 qf[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
-        qf[s] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + 16 * s + 8 * lh);
+    for (int s = 0; s < 4; ++s) {
+        const bf16x8 raw = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + 16 * s + 8 * lh);
+        union { bf16x8 v; uint32_t w[4]; } sc;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            sc.w[j] = equss::pack_bf16(equss::bf2f((u16)raw[2 * j]) * a.c, equss::bf2f((u16)raw[2 * j + 1]) * a.c);
+        qf[s] = sc.v;
+    }
+    // A fifth k step carries the softmax reference: K side = 1 in its first slot, Q side = -m_run there
+    // (both zero elsewhere), so S^T comes out of the matrix pipe as  q.k * scale * log2(e) - m_run  and
+    // goes straight into exp2.  m_run is kept bf16-representable; any reference works as long as the
+    // same one is used for every key of a query between two rescalings.
+    union { bf16x8 v; uint32_t w[4]; } kx, qx;
+    kx.w[0] = lh == 0 ? 0x00003F80u : 0u; kx.w[1] = 0u; kx.w[2] = 0u; kx.w[3] = 0u;
+    qx.w[0] = 0u; qx.w[1] = 0u; qx.w[2] = 0u; qx.w[3] = 0u;
 
     // ---- K/V staging plan: a tile is 8 pieces of 8 rows per operand; piece p of K and of V is moved
     // by wave p % NW (with 8 waves: one piece each).  Only the ragged last tile needs its row index
@@ -110,22 +125,26 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
     for (int dt = 0; dt < 2; ++dt)
         v_off[dt] = (4 * lh + vq) * 128 + (((4 * dt + 2 * vg + (vp >> 1)) ^ vsw) * 16) + (vp & 1) * 8;
 
+    const int xhalf = (lane ^ 32) << 2;   // ds_bpermute address of the lane holding the other 16 keys of the same query
     f32x16 o0 = {0.f}, o1 = {0.f};  // O^T: d tile 0 / 1, lane = query
 #pragma unroll
     for (int i = 0; i < 16; ++i) { o0[i] = 0.f; o1[i] = 0.f; }
-    float m_run = -__builtin_inff();
+    float m_run = 0.f;   // reference exponent (log2 domain), set from the first tile
     float l_run = 0.f;
-    const float c = a.c;
 
     // One key tile: S^T, online softmax, O^T update.
-    auto tile = [&](int t, bool masked) {
-        const char* kb = smem + (t & 1) * kStage;
+    // `buf` (which staging buffer holds the tile) is a compile-time constant so that every LDS address
+    // below is a per-lane base plus an immediate offset.
+    auto tile = [&](int t, bool masked, auto buf) {
+        const char* kb = smem + decltype(buf)::value * kStage;
         const char* vb = kb + kTile;
 
         // ---- S^T = K Q^T for the two 32-key tiles --------------------------------------------
         f32x16 s0, s1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
+        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx.v, qx.v, s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx.v, qx.v, s1, 0, 0, 0);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb + k_off[s]);
@@ -156,21 +175,33 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s0[r]);
 #pragma unroll
         for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s1[r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float m_new = fmaxf(m_run, mloc);
-        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        const float mc = m_new * c;
-        m_run = m_new;
+        mloc = fmaxf(mloc, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xhalf, __builtin_bit_cast(int, mloc))));
+        // Lazy rescaling: the reference follows the true maximum only when that exceeds it by more than 8
+        // (p then stays <= 256, harmless in fp32 / bf16), so on most tiles O is not touched and the scores
+        // need no subtraction at all.  The choice is per wave; the first tile always sets the reference.
+        if (t == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
+            asm volatile("" ::: "memory");   // keep this a real branch
+            const float grow = fmaxf(mloc, t == 0 ? -__builtin_inff() : 0.f);   // never lower the reference later
+            const u16 mb = equss::f2bf(m_run + (grow > -__builtin_inff() ? grow : 0.f));
+            const float m_new = equss::bf2f(mb);
+            const float shift = m_new - m_run;         // >= 0 except possibly on the first tile
+            const float alpha = __builtin_amdgcn_exp2f(-shift);
+            m_run = m_new;
+            qx.w[0] = lh == 0 ? (uint32_t)(mb ^ 0x8000u) : 0u;   // -m_run as bf16 in the first slot
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] -= shift; s1[r] -= shift; }
+        }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], c, -mc));
-            s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], c, -mc));
+            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
             psum += s0[r] + s1[r];
         }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
+        l_run += psum;
         }
 
         // ---- O^T += V^T P^T: P fragments straight from the S^T registers ----------------------
@@ -200,11 +231,16 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
 
     stage(0, 0);
     const int full_tiles = a.N / KV;  // tiles whose 64 keys are all valid
-    for (int t = 0; t < a.ntiles; ++t) {
+    for (int t = 0; t < a.ntiles; t += 2) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (DIAG != 3 || t == 0) { if (t + 1 < a.ntiles) stage((t + 1) & 1, t + 1); }  // DIAG 3: stage once
-        if (wave_active) tile(t, t >= full_tiles);
+        if (t + 1 < a.ntiles) stage(1, t + 1);
+        if (wave_active) tile(t, t >= full_tiles, std::integral_constant<int, 0>());
+        if (t + 1 >= a.ntiles) break;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (t + 2 < a.ntiles) stage(0, t + 2);
+        if (wave_active) tile(t + 1, t + 1 >= full_tiles, std::integral_constant<int, 1>());
     }
 
     // ---- normalise and store: lane (query, half) holds d = 32 dt + 8 g + 4 lh + 0..3 -----------
