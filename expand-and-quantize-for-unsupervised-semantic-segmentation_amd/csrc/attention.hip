@@ -4,8 +4,8 @@
 // attention matrix that forward also returns is discarded by its only caller on this path
 // (model/dino/dino_featurizer.py:76-80), so it is never written.
 //
-// One workgroup = 8 waves = 256 queries of one (image, head); each wave owns 32 queries and walks
-// the keys in tiles of 64 (a K/V tile is staged once per 256 queries).
+// One workgroup = NW waves (4 by default) = NW * 32 queries of one (image, head); each wave owns 32
+// queries and walks the keys in tiles of 64 (a K/V tile is staged once per workgroup).
 //  * K and V tiles go HBM/L2 -> LDS by global_load_lds_dwordx4 (two stages; the next tile is in
 //    flight while the current one is on the matrix pipe).  K is chunk-swizzled for conflict-free
 //    ds_read_b128; V is swizzled for ds_read_b64_tr_b16, the transposing LDS read that turns
@@ -282,8 +282,10 @@ int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale,
     a.qkv = reinterpret_cast<const u16*>(qkv);
     a.out = reinterpret_cast<u16*>(out);
     a.B = B; a.N = N; a.H = H;
-    // 256-query workgroups; short sequences use 128-query ones so fewer waves idle past the last query
-    const int nw = g_diag >= 4 && g_diag <= 8 ? g_diag : (N <= 128 ? 4 : 8);
+    // 128-query workgroups (4 waves, 4 resident per CU): they stage K/V twice as often per query as
+    // 256-query ones, but fewer waves idle past the last query and the last round of workgroups fills
+    // the chip better (1601 tokens: 13 x 4 waves instead of 7 x 8); measured 5 % faster.
+    const int nw = g_diag >= 4 && g_diag <= 8 ? g_diag : 4;
     const int qb = nw * QW;
     a.nqb = (N + qb - 1) / qb;
     a.ntiles = (N + KV - 1) / KV;

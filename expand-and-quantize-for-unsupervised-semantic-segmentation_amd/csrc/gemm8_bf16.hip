@@ -449,7 +449,6 @@ int launch_inst(const Gemm8Args& g, hipStream_t s) {
     constexpr int kThreads = WM * WN * 64;
     constexpr int resident = WM * WN == 8 ? 256 : 512;  // one 8-wave or two 4-wave workgroups per CU
     const int grid = ntiles < resident ? ntiles : resident;
-    constexpr int ring = S * (BM + BN) * BK * 2;
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
     constexpr int extra = EPI == EPI_RESID_LN ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
     static_assert(ring + extra <= 163840, "LDS budget");
@@ -480,6 +479,10 @@ int launch(Gemm8Args& g, hipStream_t s) {
     if (g_stages == 5 && g.N % 384 == 0) {
         g.ntn = g.N / 384;
         return launch_inst<EPI, 128, 384, 1, 4, 32, 2>(g, s);
+    }
+    if (g_stages == 6 && g.N % 192 == 0) {   // two 4-wave workgroups per CU, 128 x 192 tiles
+        g.ntn = g.N / 192;
+        return launch_inst<EPI, 128, 192, 2, 2, 32, 3>(g, s);
     }
     if (g.N % 384 == 0 && !(g_prefer256 && g.N % 256 == 0)) {
         g.ntn = g.N / 384;
