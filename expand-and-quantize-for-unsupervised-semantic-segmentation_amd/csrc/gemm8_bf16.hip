@@ -449,6 +449,7 @@ int launch_inst(const Gemm8Args& g, hipStream_t s) {
     constexpr int kThreads = WM * WN * 64;
     constexpr int resident = WM * WN == 8 ? 256 : 512;  // one 8-wave or two 4-wave workgroups per CU
     const int grid = ntiles < resident ? ntiles : resident;
+    constexpr int ring = S * (BM + BN) * BK * 2;
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
     constexpr int extra = EPI == EPI_RESID_LN ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
     static_assert(ring + extra <= 163840, "LDS budget");
