@@ -48,7 +48,7 @@ __device__ __forceinline__ bf16x4 ds_read_tr16(const char* p) {
 }
 
 // NW = waves per workgroup (NW * 32 queries of one (image, head)).
-template <int DIAG, int NW>
+template <int NW>
 __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a) {
     constexpr int QB = NW * QW;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,10 +166,6 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
             }
         }
         // ---- online softmax ------------------------------------------------------------------
-        if constexpr (DIAG == 1) {  // timing diagnostic: skip the softmax arithmetic
-#pragma unroll
-            for (int r = 0; r < 16; ++r) l_run += s0[r] * 1e-30f;
-        } else {
         float mloc = s0[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s0[r]);
@@ -202,11 +198,10 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
             psum += s0[r] + s1[r];
         }
         l_run += psum;
-        }
 
         // ---- O^T += V^T P^T: P fragments straight from the S^T registers ----------------------
 #pragma unroll
-        for (int u = 0; u < (DIAG == 2 ? 0 : 2); ++u) {  // DIAG 2: skip P V
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
             for (int sp = 0; sp < 2; ++sp) {
                 union { bf16x8 v; uint32_t w[4]; } pf;
@@ -265,11 +260,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
     }
 }
 
-int g_diag = 0;
+int g_waves = 0;  // developer override of the waves per workgroup (0 = default)
 
 }  // namespace
 
-extern "C" void equss_dev_attn_diag(int d) { g_diag = d; }
+extern "C" void equss_dev_attn_diag(int d) { g_waves = d; }  // tuning knob, not part of the ABI
 
 namespace equss {
 
@@ -285,7 +280,7 @@ int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale,
     // 128-query workgroups (4 waves, 4 resident per CU): they stage K/V twice as often per query as
     // 256-query ones, but fewer waves idle past the last query and the last round of workgroups fills
     // the chip better (1601 tokens: 13 x 4 waves instead of 7 x 8); measured 5 % faster.
-    const int nw = g_diag >= 4 && g_diag <= 8 ? g_diag : 4;
+    const int nw = g_waves == 8 ? 8 : 4;
     const int qb = nw * QW;
     a.nqb = (N + qb - 1) / qb;
     a.ntiles = (N + KV - 1) / KV;
@@ -293,10 +288,8 @@ int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale,
     const long grid = (long)a.nqb * B * H;
     if (grid > 0x7fffffffL) return fail(EQUSS_E_SHAPE, "attention_bf16: grid too large");
     switch (nw) {
-        case 8: hipLaunchKernelGGL((attention_kernel<0, 8>), dim3((unsigned)grid), dim3(512), 2 * kStage, s, a); break;
-        case 7: hipLaunchKernelGGL((attention_kernel<0, 7>), dim3((unsigned)grid), dim3(448), 2 * kStage, s, a); break;
-        case 6: hipLaunchKernelGGL((attention_kernel<0, 6>), dim3((unsigned)grid), dim3(384), 2 * kStage, s, a); break;
-        default: hipLaunchKernelGGL((attention_kernel<0, 4>), dim3((unsigned)grid), dim3(256), 2 * kStage, s, a); break;
+        case 8: hipLaunchKernelGGL(attention_kernel<8>, dim3((unsigned)grid), dim3(512), 2 * kStage, s, a); break;
+        default: hipLaunchKernelGGL(attention_kernel<4>, dim3((unsigned)grid), dim3(256), 2 * kStage, s, a); break;
     }
     return check_launch("attention_kernel");
 }

@@ -301,6 +301,26 @@ __global__ __launch_bounds__(256) void probe_loss_reduce(const float* __restrict
     }
 }
 
+// confusion[pred, label] += 1 over pixels whose label and prediction both lie in [0, num_classes)
+// (UnSegMetrics.update, model/metric.py:45-58).  Per-workgroup histogram in LDS, then one 64-bit
+// integer atomic per non-empty bin: integer sums, so the result does not depend on the order.
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ preds,
+                                                       const int64_t* __restrict__ label,
+                                                       unsigned long long* __restrict__ confusion, int64_t n,
+                                                       int num_classes, int bins) {
+    extern __shared__ unsigned int hist[];
+    for (int i = threadIdx.x; i < bins; i += 256) hist[i] = 0u;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int64_t p = preds[i], l = label[i];
+        if (l >= 0 && l < num_classes && p >= 0 && p < num_classes) atomicAdd(&hist[(int)p * num_classes + (int)l], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < bins; i += 256)
+        if (hist[i]) atomicAdd(&confusion[i], (unsigned long long)hist[i]);
+}
+
 inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 }  // namespace
@@ -363,4 +383,20 @@ extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float*
         rc = equss::check_launch("probe_loss_reduce");
     }
     return rc;
+}
+
+extern "C" int equss_confusion_update(const int64_t* preds, const int64_t* label, int64_t* confusion, int64_t n,
+                                      int num_classes, int num_pred_classes, void* stream) {
+    if (!preds || !label || !confusion) return equss::fail(EQUSS_E_NULL, "equss_confusion_update: null pointer argument");
+    if (n < 0 || num_classes < 1 || num_pred_classes < num_classes || (int64_t)num_classes * num_pred_classes > 8192)
+        return equss::fail(EQUSS_E_SHAPE, "equss_confusion_update: n=%lld, %d classes, %d predicted classes (at most 8192 bins)",
+                           (long long)n, num_classes, num_pred_classes);
+    if (n == 0) return EQUSS_OK;
+    const int bins = num_classes * num_pred_classes;
+    int64_t blocks = (n + 256 * 16 - 1) / (256 * 16);
+    if (blocks > 2048) blocks = 2048;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(confusion_kernel, dim3((unsigned)blocks), dim3(256), bins * sizeof(unsigned int), s, preds, label,
+                       reinterpret_cast<unsigned long long*>(confusion), n, num_classes, bins);
+    return equss::check_launch("confusion_kernel");
 }

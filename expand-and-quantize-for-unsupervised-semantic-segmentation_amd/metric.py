@@ -19,6 +19,7 @@ import torch
 import torch.nn as nn
 from scipy.optimize import linear_sum_assignment
 
+from . import native
 from .dist_utils import all_reduce_tensor
 
 __all__ = ["UnSegMetrics"]
@@ -47,7 +48,11 @@ class UnSegMetrics(nn.Module):
 
     @torch.no_grad()
     def update(self, preds: torch.Tensor, label: torch.Tensor):
-        """One bincount over label * n_pred + pred, no host sync (metric.py:45-58)."""
+        """Accumulate the confusion matrix (metric.py:45-58), no host sync: one HIP kernel on the GPU,
+        one bincount over label * n_pred + pred on CPU tensors."""
+        if self.confusion_matrix.is_cuda and preds.is_cuda and label.is_cuda:
+            native.confusion_update(self.confusion_matrix, preds, label, self.num_classes)
+            return
         preds = preds.reshape(-1)
         label = label.reshape(-1)
         n_pred = self.num_classes + self.extra_classes

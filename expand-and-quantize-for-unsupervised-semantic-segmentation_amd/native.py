@@ -21,7 +21,7 @@ EXPORTED_SYMBOLS = [
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
-    "equss_probe_workspace_bytes", "equss_probe_eval",
+    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
 ]
 
 
@@ -87,6 +87,8 @@ def _declare(lib):
     lib.equss_expand_head.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]
     lib.equss_probe_workspace_bytes.restype = c_sz
     lib.equss_probe_workspace_bytes.argtypes = [c_int] * 5
+    lib.equss_confusion_update.restype = c_int
+    lib.equss_confusion_update.argtypes = [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]
     lib.equss_probe_eval.restype = c_int
     lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
@@ -395,3 +397,18 @@ def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster,
     if want_norm:
         return lin, clu, losses, norm
     return lin, clu, losses
+
+
+def confusion_update(confusion, preds, label, num_classes):
+    """confusion (n_pred, num_classes) int64 on the GPU += counts of (pred, label) pairs with both in
+    [0, num_classes)  (model/metric.py:45-58)."""
+    _need_cuda(confusion, preds, label)
+    if confusion.dtype != torch.int64 or not confusion.is_contiguous() or confusion.shape[1] != num_classes:
+        raise ValueError("confusion_update: confusion must be a contiguous (n_pred, num_classes) int64 tensor")
+    preds = preds.reshape(-1).long().contiguous()
+    label = label.reshape(-1).long().contiguous()
+    if preds.numel() != label.numel():
+        raise ValueError("confusion_update: preds and label differ in size")
+    _check(load_library().equss_confusion_update(_ptr(preds), _ptr(label), _ptr(confusion), preds.numel(),
+                                                 int(num_classes), int(confusion.shape[0]), _stream(confusion)),
+           "equss_confusion_update")

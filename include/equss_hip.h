@@ -233,6 +233,14 @@ int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, co
                      float* feature_norm, void* workspace, size_t workspace_bytes, int B, int h, int w, int D,
                      int H, int W, int n_linear, int n_cluster, void* stream);
 
+/* Confusion-matrix accumulation of the eval loop: UnSegMetrics.update (model/metric.py:45-58).
+ *   confusion (num_pred_classes, num_classes) int64, row-major, updated in place:
+ *   confusion[pred, label] += 1 for every i < n with 0 <= label[i] < num_classes and
+ *   0 <= preds[i] < num_classes (both int64; the reference applies the same upper bound to both, :49).
+ * Integer atomics only, so the result is independent of scheduling. */
+int equss_confusion_update(const int64_t* preds, const int64_t* label, int64_t* confusion, int64_t n,
+                           int num_classes, int num_pred_classes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
