@@ -534,7 +534,6 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
     g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1; g.nostore = g_nostore;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
     if (g_stages == 5) return launch_inst<EPI_RESID_LN, 128, 384, 1, 4, 32, 2>(g, s);
-    if (g_stages == 7) return launch_inst<EPI_RESID_LN, 64, 384, 1, 4, 32, 2>(g, s);   // two 4-wave workgroups per CU
     return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);
 }
 
