@@ -238,7 +238,7 @@ __global__ __launch_bounds__(kPqThreads, 2) void pq_assign_kernel(const PqArgs a
 }
 
 // ---------------------------------------------------------------------------------------------
-// Screened search (l2 normalisation, d = 128, K * d * 2 <= 64 KiB): the exact fp32 search above
+// Screened search (l2 normalisation, d = 128, K * d * 2 <= 128 KiB): the exact fp32 search above
 // spends 2 K flop per 8 bytes of row traffic and is bound by the fp32 matrix rate, not by HBM.
 // Here an fp16 MFMA pass scores every codeword with a proven error bound, and only codewords whose
 // fp16 score is within that bound of the best one are re-scored in exact fp32 -- on typical data
@@ -282,19 +282,21 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
 
 constexpr int kScrCap = 8;      // survivors listed per row; more -> exact scan of all K for that row
 constexpr float kScrE = 0.0009765625f + 0.0000152587890625f;  // 2^-10 + 2^-16
-constexpr int kScrThreads = 768;    // 12 independent waves per workgroup (three per SIMD, <= 168 VGPRs)
 constexpr int kScrRows = 16;        // rows per wave tile (v_mfma_f32_16x16x32_f16)
 constexpr int kScrWaveLds = kScrRows * 256 + kScrRows * 4 * 2 + kScrRows * kScrCap * 4;
 
-template <int D>
-__global__ __launch_bounds__(kScrThreads, 3) void pq_screen_kernel(const PqArgs a) {
+// NWAVES independent waves per workgroup: 12 (three per SIMD, <= 168 VGPRs) when the fp16 codebook
+// takes <= 64 KiB of LDS, 6 when it takes up to 128 KiB (K = 512).  MW = 32-bit survivor-mask words
+// per lane = K / 128.
+template <int D, int NWAVES, int MW>
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_kernel(const PqArgs a) {
+    constexpr int kScrThreads = NWAVES * 64;
     static_assert(D == 128, "fragment and swizzle arithmetic below is written for d = 128");
     constexpr int LPR = D / 4;            // lanes holding one row as float4 each
     constexpr int RPI = 64 / LPR;         // rows per wave-wide load
     constexpr int NI = kScrRows / RPI;    // float4 per lane per tile
     constexpr int KB = D / 32;            // MFMA k blocks
     constexpr int ROWB = D * 2;           // bytes per fp16 row
-    constexpr int NWAVES = kScrThreads / 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -406,12 +408,14 @@ __global__ __launch_bounds__(kScrThreads, 3) void pq_screen_kernel(const PqArgs 
         const float thr = best - T;   // (NaN scores compare false everywhere: the row ends with index 0)
 
         // ---- pass 2: recompute the scores; one bit per (codeword of this lane) that survives --------------
-        // Branch-free: mask = 2 mask + (score >= thr), two 32-bit words for up to 64 codewords per lane
-        // (K <= 256).  Value n of a word (n = 4 (ct - ct0) + e) ends at bit nv - 1 - n.
+        // Branch-free: mask = 2 mask + (score >= thr), one 32-bit word per 8 codeword tiles (32 codewords
+        // of this lane).  Value n of a word (n = 4 (ct - ct0) + e) ends at bit nv - 1 - n.
         const int nct = K / 16;
-        uint32_t mk[2] = {0u, 0u};
+        uint32_t mk[MW];
 #pragma unroll
-        for (int w = 0; w < 2; ++w) {
+        for (int w = 0; w < MW; ++w) mk[w] = 0u;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) {
             const int ct_end = min(nct, 8 * w + 8);
             for (int ct = 8 * w; ct < ((diag & 1) ? 0 : ct_end); ct += 2) {
                 const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
@@ -421,22 +425,27 @@ __global__ __launch_bounds__(kScrThreads, 3) void pq_screen_kernel(const PqArgs 
                 for (int e = 0; e < 4; ++e) mk[w] = (mk[w] << 1) | (a1[e] >= thr ? 1u : 0u);
             }
         }
-        const int nv0 = 4 * min(nct, 8), nv1 = 4 * max(nct - 8, 0);
         auto codeword = [&](int w, int bit) {   // bit of word w -> codeword index
-            const int n = (w == 0 ? nv0 : nv1) - 1 - bit;
+            const int n = 4 * min(nct - 8 * w, 8) - 1 - bit;
             return 16 * (8 * w + (n >> 2)) + 4 * q + (n & 3);
         };
-        const int mine = __popc(mk[0]) + __popc(mk[1]);
+        int mine = 0;
+#pragma unroll
+        for (int w = 0; w < MW; ++w) mine += __popc(mk[w]);
         int total = mine + __shfl_xor(mine, 16, 64);
         total += __shfl_xor(total, 32, 64);
         int hit = -1;
-        if (mine == 1) hit = mk[0] ? codeword(0, 31 - __clz(mk[0])) : codeword(1, 31 - __clz(mk[1]));
+        if (mine == 1) {
+#pragma unroll
+            for (int w = 0; w < MW; ++w)
+                if (mk[w]) hit = codeword(w, 31 - __clz(mk[w]));
+        }
         hit = max(hit, __shfl_xor(hit, 16, 64));
         hit = max(hit, __shfl_xor(hit, 32, 64));
         if (lane < kScrRows) fin_s[lane] = max(hit, 0);   // right when exactly one codeword survived
         if (total >= 2 && mine > 0 && !(diag & 8)) {       // several survivors: list them for the exact pass
 #pragma unroll
-            for (int w = 0; w < 2; ++w) {
+            for (int w = 0; w < MW; ++w) {
                 uint32_t m = mk[w];
                 while (m) {
                     const int bit = 31 - __clz(m);
@@ -721,24 +730,21 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
     a.WK = pl.WK; a.WR = pl.WR; a.RT = pl.RT;
     a.ntiles = (rows + pl.R - 1) / pl.R;
     int gx = (256 + num_pq - 1) / num_pq;  // one resident workgroup per CU
-    const bool screened = (g_pq_mode & 15) != 1 && d == 128 && normalize == EQUSS_NORM_L2 && (size_t)K * d * 2 <= 65536;  // (K % 32 == 0 already checked)
+    const bool screened = (g_pq_mode & 15) != 1 && d == 128 && normalize == EQUSS_NORM_L2 && (size_t)K * d * 2 <= 131072;
     if (screened) {
         a.ntiles = (rows + kScrRows - 1) / kScrRows;
         a.WK = g_pq_mode >> 4;  // developer timing switches (0 in normal use)
-        const int waves = kScrThreads / 64;
+        const bool small = (size_t)K * d * 2 <= 65536;
+        const int waves = small ? 12 : 6;
         if (gx > (a.ntiles + waves - 1) / waves) gx = (a.ntiles + waves - 1) / waves;
         if (gx > kMaxGridX) gx = kMaxGridX;
         const size_t lds = (size_t)K * d * 2 + (K + 16) * 4 + (size_t)waves * kScrWaveLds;
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(pq_screen_kernel<128>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
-                return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve LDS for the screened search");
-            attr_done = true;
-        }
+        void (*kern)(const PqArgs) = !small ? pq_screen_kernel<128, 6, 4> : (K <= 128 ? pq_screen_kernel<128, 12, 1> : pq_screen_kernel<128, 12, 2>);
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
+            return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve LDS for the screened search");
         {
             equss::ProfScope ps(EQUSS_K_PQ_ASSIGN, s);
-            hipLaunchKernelGGL(pq_screen_kernel<128>, dim3(gx, num_pq), dim3(kScrThreads), lds, s, a);
+            hipLaunchKernelGGL(kern, dim3(gx, num_pq), dim3(waves * 64), lds, s, a);
             rc = equss::check_launch("pq_screen_kernel");
         }
         if (rc) return rc;

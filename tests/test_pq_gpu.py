@@ -118,6 +118,7 @@ def _adversarial_case(kind, rows, k, seed):
 
 
 @pytest.mark.parametrize("kind,rows,k", [("random", 1000, 256), ("random", 333, 128), ("random", 777, 64),
+                                         ("random", 500, 512), ("clustered", 300, 512),
                                          ("clustered", 600, 256), ("duplicates", 500, 128),
                                          ("on_codeword", 900, 256)])
 def test_screened_search_equals_exact_search(kind, rows, k, native, oracle, dev):
