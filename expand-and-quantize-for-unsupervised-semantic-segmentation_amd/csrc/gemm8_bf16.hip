@@ -26,7 +26,7 @@ struct Gemm8Args {
     const u16* W; int64_t ldw;
     const float* bias;
     void* out; int64_t ldo;
-    int M, N, K, ntn, nostore;
+    int M, N, K, ntn;
     // residual + LayerNorm epilogue (EPI_RESID_LN): x (M, N) fp32 is updated in place, ln receives
     // LayerNorm(x) in bf16 (or is skipped when null)
     float* x; int64_t ldx;
@@ -157,10 +157,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
     auto issue_one = [&]() {
         if (issued >= total) return;
         char* base = smem + i_buf * kStageBytes;
-        if (!(g.nostore & 4)) {
 #pragma unroll
-            for (int i = 0; i < PW; ++i) glds16(src[i] + (size_t)i_kt * BK, base + (i * NW + wave) * 1024);
-        }
+        for (int i = 0; i < PW; ++i) glds16(src[i] + (size_t)i_kt * BK, base + (i * NW + wave) * 1024);
         ++issued;
         i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
         if (++i_kt == nk) {
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = m0 + wm * TM + mt * 16 + fr;
                     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    if (m < g.M && !(g.nostore & 8)) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
+                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
                     o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
                     acc[nt][mt] = o;
                 }
@@ -282,19 +280,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 bf16x8 af[MT], wf[NT];
-                if (g.nostore & 2) {
-#pragma unroll
-                    for (int i = 0; i < MT; ++i) { af[i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(af[i])); }
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) { wf[i] = bf16x8{1, 2, 3, 4, 5, 6, 7, 8}; asm volatile("" : "+v"(wf[i])); }
-                } else {
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
                     af[i] = *reinterpret_cast<const bf16x8*>(base + a_base + i * 16 * ROWB + c_off[ks]);
 #pragma unroll
                 for (int i = 0; i < NT; ++i)
                     wf[i] = *reinterpret_cast<const bf16x8*>(base + w_base + i * 16 * ROWB + c_off[ks]);
-                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -322,7 +313,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = wn * TN + nt * 16 + fq * 4;
                     const f32x4 v = acc[nt][mt];
-                    if (m < g.M && !(g.nostore & 1)) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
                     s1[mt] += (v.x + v.y) + (v.z + v.w);
                     s2[mt] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
                 }
@@ -365,7 +356,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         const int row = idx / OCH, ch = idx % OCH;
                         const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                         const int m = m0 + wm * TM + pass * RP + row;
-                        if (m < g.M && !(g.nostore & 16)) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * TN + ch * 8) = d;
+                        if (m < g.M) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * TN + ch * 8) = d;
                     }
                     asm volatile("" ::: "memory");
                 }
@@ -394,7 +385,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
             static_assert(RP * OCH % 64 == 0, "epilogue chunking");
             // A full tile issues exactly NST stores per wave, which lets the waits that follow leave them
             // in flight; the ragged last row-tile masks stores, so it falls back to the stricter wait.
-            const bool full = m0 + BM <= g.M && !(g.nostore & 1);
+            const bool full = m0 + BM <= g.M;
             epi_mark = full ? issued : 0;
             const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
             char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / NW);
@@ -429,7 +420,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                     const int row = idx / OCH, ch = idx % OCH;
                     const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                     const int m = m0 + wm * TM + pass * RP + row;
-                    if (g.nostore & 1) { asm volatile("" ::"v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w)); continue; }
                     if (full || m < g.M)
                         *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n0 + wn * TN + ch * 8) = d;
                 }
@@ -441,7 +431,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
 
 int g_stages = 2;
 int g_prefer256 = 1;  // 256 x 256 tiles when N allows (131 flop/B instead of 96)
-int g_nostore = 0;
 
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
 int launch_inst(const Gemm8Args& g, hipStream_t s) {
@@ -510,7 +499,7 @@ int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const flo
     Gemm8Args g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
-    g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.ntn = 0; g.nostore = g_nostore;
+    g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.ntn = 0;
     g.x = nullptr; g.ldx = 0; g.gamma = nullptr; g.beta = nullptr; g.ln = nullptr; g.ld_ln = 0; g.eps = 0.f;
     switch (epilogue) {
         case EQUSS_EPI_BF16: return launch<EQUSS_EPI_BF16>(g, s);
@@ -531,7 +520,7 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
     Gemm8Args g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
-    g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1; g.nostore = g_nostore;
+    g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
     if (g_stages == 5) return launch_inst<EPI_RESID_LN, 128, 384, 1, 4, 32, 2>(g, s);
     return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);
@@ -539,4 +528,4 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
 
 }  // namespace equss
 
-extern "C" void equss_dev_gemm_stages(int s) { g_stages = s & 7; g_prefer256 = (s >> 3) & 1; g_nostore = s >> 4; }  // tuning knob, not part of the ABI
+extern "C" void equss_dev_gemm_stages(int s) { g_stages = s & 7; g_prefer256 = (s >> 3) & 1; }  // tuning knob, not part of the ABI

@@ -394,8 +394,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
 
         // ---- pass 1: best and second-best score per row ------------------------------------------------
         float best = -__builtin_inff();
-        const int diag = a.WK;
-        for (int ct = 0; ct < ((diag & 2) ? 0 : K / 16); ct += 2) {
+        for (int ct = 0; ct < K / 16; ct += 2) {
             const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
             best = fmaxf(fmaxf(best, fmaxf(a0.x, a0.y)), fmaxf(a0.z, a0.w));
             best = fmaxf(fmaxf(best, fmaxf(a1.x, a1.y)), fmaxf(a1.z, a1.w));
@@ -417,7 +416,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
 #pragma unroll
         for (int w = 0; w < MW; ++w) {
             const int ct_end = min(nct, 8 * w + 8);
-            for (int ct = 8 * w; ct < ((diag & 1) ? 0 : ct_end); ct += 2) {
+            for (int ct = 8 * w; ct < ct_end; ct += 2) {
                 const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mk[w] = (mk[w] << 1) | (a0[e] >= thr ? 1u : 0u);
@@ -443,7 +442,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
         hit = max(hit, __shfl_xor(hit, 16, 64));
         hit = max(hit, __shfl_xor(hit, 32, 64));
         if (lane < kScrRows) fin_s[lane] = max(hit, 0);   // right when exactly one codeword survived
-        if (total >= 2 && mine > 0 && !(diag & 8)) {       // several survivors: list them for the exact pass
+        if (total >= 2 && mine > 0) {                      // several survivors: list them for the exact pass
 #pragma unroll
             for (int w = 0; w < MW; ++w) {
                 uint32_t m = mk[w];
@@ -459,7 +458,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
 
         // ---- exact fp32 re-scoring of rows with several survivors: a half-wave per row ---------------
         // dist = (|zn|^2 + |cn|^2) - 2 <zn, cn>, smaller distance wins, then smaller index.
-        if (__builtin_amdgcn_ballot_w64(total >= 2) != 0 && !(diag & 16)) {
+        if (__builtin_amdgcn_ballot_w64(total >= 2) != 0) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) {
                 const int r = i * RPI + rsub;
@@ -503,7 +502,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
                 const f32x4 e = *reinterpret_cast<const f32x4*>(a.gather + ((size_t)p * K + k) * D + 4 * c4);
                 f32x4 df; df.x = e.x - zn.x; df.y = e.y - zn.y; df.z = e.z - zn.z; df.w = e.w - zn.w;
                 loss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
-                if (a.zq && !(diag & 4)) {
+                if (a.zq) {
                     f32x4 o; o.x = zn.x + df.x; o.y = zn.y + df.y; o.z = zn.z + df.z; o.w = zn.w + df.w;
                     *reinterpret_cast<f32x4*>(a.zq + (size_t)grow * a.ld_zq + (size_t)p * D + 4 * c4) = o;
                 }
@@ -730,10 +729,9 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
     a.WK = pl.WK; a.WR = pl.WR; a.RT = pl.RT;
     a.ntiles = (rows + pl.R - 1) / pl.R;
     int gx = (256 + num_pq - 1) / num_pq;  // one resident workgroup per CU
-    const bool screened = (g_pq_mode & 15) != 1 && d == 128 && normalize == EQUSS_NORM_L2 && (size_t)K * d * 2 <= 131072;
+    const bool screened = g_pq_mode != 1 && d == 128 && normalize == EQUSS_NORM_L2 && (size_t)K * d * 2 <= 131072;
     if (screened) {
         a.ntiles = (rows + kScrRows - 1) / kScrRows;
-        a.WK = g_pq_mode >> 4;  // developer timing switches (0 in normal use)
         const bool small = (size_t)K * d * 2 <= 65536;
         const int waves = small ? 12 : 6;
         if (gx > (a.ntiles + waves - 1) / waves) gx = (a.ntiles + waves - 1) / waves;

@@ -29,7 +29,7 @@ for diag in [int(a) for a in sys.argv[1:]] or [0]:
     us = e0.elapsed_time(e1) / 10 * 1e3
     print(f"attention diag {diag}: {us:.1f} us  {4.0 * B * N * N * 384 / us / 1e6:.1f} TF")
 nat.load_library().equss_dev_attn_diag(ctypes.c_int(0))
-for mode in (0, 1, 256, 128, 16):
+for mode in (0, 1, 0):   # 0 = screened search where it applies, 1 = exhaustive fp32 search
     nat.load_library().equss_dev_pq_mode(ctypes.c_int(mode))
     nat.pq_assign(code, books, "l2")
     e0.record()

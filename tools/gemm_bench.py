@@ -11,7 +11,7 @@ M = 64 * 1601
 SHAPES = [("qkv", M, 1152, 384, 0), ("proj", M, 384, 384, 0), ("fc1", M, 1536, 384, 1), ("fc2", M, 384, 1536, 0),
           ("head2", 64 * 1600, 1024, 768, 3)]
 variants = [int(v) for v in sys.argv[1:]] or [0]
-STAGES = {206: 6 + 8, 216: 6 + 8 + 16, 63: 3 + 8, 64: 4 + 8, 74: 4 + 8 + 16, 205: 5 + 8, 215: 5 + 8 + 16, 235: 5 + 8 + 16 * 3, 275: 5 + 8 + 16 * 7, 101: 2 + 8 + 16 * 1, 102: 2 + 8 + 16 * 2, 103: 2 + 8 + 16 * 3, 104: 2 + 8 + 16 * 4, 105: 2 + 8 + 16 * 5, 107: 2 + 8 + 16 * 7, 106: 2 + 8 + 16 * 6, 62: 2 + 8, 72: 2 + 8 + 16, 32: 2, 33: 3, 34: 4, 42: 2 + 16, 44: 4 + 16, 52: 2 + 16 * 2, 53: 2 + 16 * 3, 54: 2 + 16 * 4, 56: 2 + 16 * 6}
+STAGES = {62: 2 + 8, 63: 3 + 8, 64: 4 + 8, 32: 2, 33: 3, 34: 4, 205: 5 + 8, 206: 6 + 8}
 torch.manual_seed(0)
 for name, m, n, k, epi in SHAPES:
     a = (torch.randn(m, k, device=dev)).to(torch.bfloat16)

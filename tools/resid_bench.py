@@ -1,6 +1,5 @@
 """Developer micro-benchmark of equss_gemm_resid_ln_bf16 (not part of the product).
-usage: python tools/resid_bench.py [diag ...]   diag bits: 1 skip x stores, 2 skip LDS fragment reads,
-4 skip ring loads, 8 skip x loads, 16 skip LayerNorm stores"""
+usage: python tools/resid_bench.py"""
 import ctypes, importlib, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -16,8 +15,7 @@ for name, k in (("proj", 384), ("fc2", 1536)):
     bias = torch.randn(384, device=dev)
     gamma, beta = torch.ones(384, device=dev), torch.zeros(384, device=dev)
     x = torch.randn(M, 384, device=dev)
-    for diag in [int(v) for v in sys.argv[1:]] or [0]:
-        lib.equss_dev_gemm_stages(ctypes.c_int(2 + 8 + 16 * diag))
+    for diag in [0]:
         for _ in range(3):
             nat.gemm_resid_ln_bf16(a, w, bias, x, gamma, beta, 1e-6)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
