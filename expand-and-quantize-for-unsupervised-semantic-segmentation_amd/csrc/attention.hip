@@ -178,7 +178,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
         if (t == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
             asm volatile("" ::: "memory");   // keep this a real branch
             const float grow = fmaxf(mloc, t == 0 ? -__builtin_inff() : 0.f);   // never lower the reference later
-            const u16 mb = equss::f2bf(m_run + (grow > -__builtin_inff() ? grow : 0.f));
+            // new reference = the maximum rounded UP to bf16: every score then comes out <= 0 and exp2 cannot
+            // overflow however large the logits are
+            const float target = m_run + (grow > -__builtin_inff() ? grow : 0.f);
+            u16 mb = equss::f2bf(target);
+            if (equss::bf2f(mb) < target) mb = (u16)(target > 0.f ? mb + 1 : mb - 1);
             const float m_new = equss::bf2f(mb);
             const float shift = m_new - m_run;         // >= 0 except possibly on the first tile
             const float alpha = __builtin_amdgcn_exp2f(-shift);

@@ -139,6 +139,26 @@ def test_attention_rescale_branch_is_exercised(native, dev):
     assert (out.cpu().double() - ref).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("gain", [6.0, 24.0])
+def test_attention_large_logits(gain, native, dev):
+    """Logits of tens to thousands (log2 units): the softmax reference is kept in bf16 and rounded up,
+    so exp2 never overflows and the result stays a convex combination of V rows."""
+    b, n, h = 1, 333, 2
+    g = _rng(12)
+    qkv = torch.from_numpy(g.standard_normal((n, 3, h, 64)).astype(np.float32))
+    qkv[:, :2] *= gain
+    qkv[:64, 1] *= 0.01            # the first key tile scores far below the later ones
+    qkv = _bf(qkv.reshape(n, -1))
+    ref = _attention_ref(qkv, b, n, h)
+    out = native.attention_bf16(qkv.to(dev), b, n, h, 0.125).cpu().double()
+    assert torch.isfinite(out).all()
+    # q is rounded to bf16 once more after the scale is folded in: logits of magnitude L carry ~L * 2^-9
+    # of extra noise (L ~ 150 / 2400 here), which shows where two keys compete closely
+    err = (out - ref).abs()
+    assert err.max() < (0.3 if gain < 10 else 1.5) and err.mean() < (5e-3 if gain < 10 else 2e-2), (float(err.max()), float(err.mean()))
+    assert out.abs().max() <= qkv.reshape(n, 3, h, 64)[:, 2].abs().max().double() + 1e-2
+
+
 def test_patch_tokens(native, dev):
     g = _rng(11)
     b, hh, ww, p, c = 2, 48, 80, 8, 384
