@@ -314,8 +314,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                     const int n = wn * TN + nt * 16 + fq * 4;
                     const f32x4 v = acc[nt][mt];
                     if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+                    // (explicit fma placement: layernorm_rowtile_kernel in vit_ops.hip repeats these sums
+                    // in the same order so that both routes give the same bits)
                     s1[mt] += (v.x + v.y) + (v.z + v.w);
-                    s2[mt] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    s2[mt] += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
                 }
                 s1[mt] += __shfl_xor(s1[mt], 16, 64); s2[mt] += __shfl_xor(s2[mt], 16, 64);
                 s1[mt] += __shfl_xor(s1[mt], 32, 64); s2[mt] += __shfl_xor(s2[mt], 32, 64);
@@ -336,7 +338,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         const float2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
                         const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / BN);
                         const float ex2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / BN);
-                        const float rstd = 1.0f / sqrtf(fmaxf(ex2 - mean * mean, 0.f) + g.eps);
+                        const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt) {
                             const int n = wn * TN + nt * 16 + fq * 4;
@@ -344,8 +346,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                             const f32x4 be = *reinterpret_cast<const f32x4*>(beta_s + n);
                             const f32x4 v = acc[nt][mt];
                             uint2 pk;
-                            pk.x = equss::pack_bf16((v.x - mean) * rstd * ga.x + be.x, (v.y - mean) * rstd * ga.y + be.y);
-                            pk.y = equss::pack_bf16((v.z - mean) * rstd * ga.z + be.z, (v.w - mean) * rstd * ga.w + be.w);
+                            pk.x = equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y));
+                            pk.y = equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w));
                             *reinterpret_cast<uint2*>(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
                         }
                     }

@@ -82,10 +82,8 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], 
             if constexpr (EPI == EQUSS_EPI_F32) {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n) = v;
             } else if constexpr (EPI == EQUSS_EPI_RESID_F32) {
-                f32x4* p = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n);
-                f32x4 o = *p;
-                o.x += v.x; o.y += v.y; o.z += v.z; o.w += v.w;
-                *p = o;
+                // the accumulators started from out + bias (see the tile loop), so they are the result
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n) = acc[nt][mt];
             } else {
                 uint2 pk;
                 pk.x = equss::pack_bf16(v.x, v.y);
@@ -171,10 +169,30 @@ __global__ __launch_bounds__(kThreads, 2) void gemm_bf16_kernel(const GemmArgs g
     int buf = 0;
     while (true) {
         f32x4 acc[4][4];  // [nt][mt], element j <-> output column n + j
+        if constexpr (EPI == EQUSS_EPI_RESID_F32) {
+            // residual epilogue: start from out + bias and accumulate onto it, the same order of fp32
+            // operations as the large-tile residual + LayerNorm kernel, so a row gets the same bits
+            // whichever of the two kernels handles it
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int nt = 0; nt < 4; ++nt) {
+                const int n = n0 + wave_n * 64 + nt * 16 + fq * 4;
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + n);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int m = m0 + wave_m * 64 + mt * 16 + fr;
+                    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(g.out) + (size_t)m * g.ldo + n);
+                    o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
+                    acc[nt][mt] = o;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         const int cm0 = m0, cn0 = n0;
         int nxt = it + nslots;
         if (VAR < 2 || nxt >= x_len) nxt = -1;

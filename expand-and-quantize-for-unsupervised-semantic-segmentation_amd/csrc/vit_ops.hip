@@ -174,11 +174,56 @@ int layernorm(const float* x, int64_t ld_x, const float* gamma, const float* bet
     return equss::check_launch("layernorm_kernel");
 }
 
+// LayerNorm of rows of width 384 with exactly the arithmetic of the fused residual + LayerNorm GEMM
+// epilogue (gemm8_bf16.hip): the same element-to-lane map (wave = 96-column group, lane = (row, 4-column
+// quad)), the same order of partial sums and the same fma placement, so a row normalised here has the
+// same bf16 bits as one normalised there.  Used for the trailing rows that leave the fused kernel.
+__global__ __launch_bounds__(256) void layernorm_rowtile_kernel(const float* __restrict__ x, int64_t ld_x,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               u16* __restrict__ out, int64_t ld_out, int rows,
+                                                               float eps) {
+    __shared__ float2 red[16][4];
+    const int lane = threadIdx.x & 63, wn = threadIdx.x >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int m = blockIdx.x * 16 + fr;
+    f32x4 v[6];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int n = wn * 96 + nt * 16 + fq * 4;
+        v[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (m < rows) v[nt] = *reinterpret_cast<const f32x4*>(x + (size_t)m * ld_x + n);
+        s1 += (v[nt].x + v[nt].y) + (v[nt].z + v[nt].w);
+        s2 += fmaf(v[nt].x, v[nt].x, v[nt].y * v[nt].y) + fmaf(v[nt].z, v[nt].z, v[nt].w * v[nt].w);
+    }
+    s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
+    s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+    if (fq == 0) red[fr][wn] = make_float2(s1, s2);
+    __syncthreads();
+    const float2 p0 = red[fr][0], p1 = red[fr][1], p2 = red[fr][2], p3 = red[fr][3];
+    const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / 384);
+    const float ex2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / 384);
+    const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + eps);
+    if (m >= rows) return;
+#pragma unroll
+    for (int nt = 0; nt < 6; ++nt) {
+        const int n = wn * 96 + nt * 16 + fq * 4;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + n);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(beta + n);
+        uint2 pk;
+        pk.x = equss::pack_bf16(fmaf((v[nt].x - mean) * rstd, ga.x, be.x), fmaf((v[nt].y - mean) * rstd, ga.y, be.y));
+        pk.y = equss::pack_bf16(fmaf((v[nt].z - mean) * rstd, ga.z, be.z), fmaf((v[nt].w - mean) * rstd, ga.w, be.w));
+        *reinterpret_cast<uint2*>(out + (size_t)m * ld_out + n) = pk;
+    }
+}
+
 // x += A W^T + bias, ln = LayerNorm(x), with the workgroup count balanced against the chip.
 // The fused kernel walks 128-row tiles with one persistent workgroup per CU, so a tile count just
 // above a multiple of 256 leaves most CUs idle for a whole extra round (64 x 1601 tokens = 801 tiles
 // = 3 rounds + 33 tiles).  Those trailing rows go through the 128 x 128-tile residual GEMM (three times
-// as many, smaller tiles, two workgroups per CU) and a LayerNorm launch of their own instead.
+// as many, smaller tiles, two workgroups per CU) and a LayerNorm launch of their own instead; both
+// repeat the fused kernel's fp32 operation order, so which route a row takes does not change its bits.
 int resid_ln_balanced(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
                       const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, int N, int K, float eps,
                       hipStream_t s) {
@@ -192,8 +237,9 @@ int resid_ln_balanced(const void* A, int64_t lda, const void* W, int64_t ldw, co
     float* x_tail = x + (size_t)m_main * ldx;
     rc = equss::gemm_bf16(a_tail, lda, W, ldw, bias, x_tail, ldx, m_tail, N, K, EQUSS_EPI_RESID_F32, s);
     if (rc || !ln) return rc;
-    return layernorm(x_tail, ldx, gamma, beta, reinterpret_cast<u16*>(ln) + (size_t)m_main * ld_ln, ld_ln, nullptr, m_tail,
-                     N, 0, eps, s);
+    hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, ldx, gamma, beta,
+                       reinterpret_cast<u16*>(ln) + (size_t)m_main * ld_ln, ld_ln, m_tail, eps);
+    return equss::check_launch("layernorm_rowtile_kernel");
 }
 
 int patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls, const float* pos,

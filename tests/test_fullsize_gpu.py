@@ -1,0 +1,67 @@
+"""Properties at the benchmark's full size (64 images of 320x320: 102 400 rows x 1024 channels, 8 x 256
+codewords), where no CPU oracle finishes in seconds: idempotence, independence of rows and of images
+(what sharding images over ranks relies on), permutation equivariance, conservation of counts."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big_case(dev):
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    code = torch.randn(64 * 1600, 1024, generator=gen).to(dev)
+    books = (torch.rand(8, 256, 128, generator=gen) - 0.5).to(dev)
+    return code, books
+
+
+def test_pq_full_size_properties(big_case, native, dev):
+    code, books = big_case
+    rows = code.shape[0]
+    idx, zq, loss = native.pq_assign(code, books)
+    assert idx.shape == (8, rows) and int(idx.min()) >= 0 and int(idx.max()) < 256
+    # z_q is the chosen raw codeword (straight-through form), sub-space by sub-space
+    gathered = torch.stack([books[p][idx[p]] for p in range(8)], dim=1).reshape(rows, 1024)
+    assert (zq - gathered).abs().max() < 3e-7
+    # conservation: the usage histogram of every sub-space sums to the number of rows
+    for p in range(8):
+        assert int(torch.bincount(idx[p], minlength=256).sum()) == rows
+    # idempotence: a codeword's nearest codeword is itself
+    idx2, zq2, _ = native.pq_assign(gathered, books)
+    assert torch.equal(idx2, idx)
+    # rows are independent: two halves, and a permutation of the rows, give the same assignment
+    a, _, la = native.pq_assign(code[: rows // 2 + 7], books)
+    b, _, lb = native.pq_assign(code[rows // 2 + 7:], books)
+    assert torch.equal(torch.cat([a, b], dim=1), idx)
+    perm = torch.randperm(rows, generator=torch.Generator(device="cpu").manual_seed(1)).to(dev)
+    ip, zp, lp = native.pq_assign(code[perm], books)
+    assert torch.equal(ip, idx[:, perm]) and torch.equal(zp, zq[perm])
+    # loss = sum of squared (codeword - normalised row); split sums add up, permutation changes only rounding
+    zn = torch.nn.functional.normalize(code.view(rows, 8, 128), dim=2)
+    want = ((gathered.view(rows, 8, 128) - zn) ** 2).sum(dim=(0, 2))
+    assert torch.allclose(loss, want, rtol=1e-4)
+    assert torch.allclose(la + lb, loss, rtol=1e-5) and torch.allclose(lp, loss, rtol=1e-5)
+    # bitwise reproducible run to run
+    i3, z3, l3 = native.pq_assign(code, books)
+    assert torch.equal(i3, idx) and torch.equal(z3, zq) and torch.equal(l3, loss)
+
+
+def test_model_full_batch_equals_per_shard_results(pkg, dev):
+    """One 64-image batch against the same images run as shards of 16 (what data-parallel ranks do).
+    Images are independent and every kernel applies the same fp32 operations in the same order to a
+    row whatever the batch -- including the trailing rows of the residual GEMMs, which take a
+    small-tile route with a LayerNorm launch of its own -- so results are bit-identical image by image."""
+    cfg = pkg.configs.S_CFG
+    m = pkg.build_model(cfg)
+    m.load_state_dict(pkg.synth.synth_pqgo_state(cfg, seed=1234), strict=True)
+    m = m.to(dev).eval()
+    img = pkg.synth.synth_images(64, 320, 320, seed=3).to(dev)
+    with torch.no_grad():
+        code, quant, (_s, _q, index), out = m.model(img=img)
+        code, quant, index = code.clone(), quant.clone(), index.clone()
+        for s in range(0, 64, 16):
+            c2, q2, (_a, _b, i2), _o = m.model(img=img[s:s + 16])
+            assert torch.equal(i2, index[:, s:s + 16]), f"indices differ for shard {s}"
+            assert torch.equal(c2, code[s:s + 16]) and torch.equal(q2, quant[s:s + 16])
+    assert index.shape == (8, 64, 40, 40)
+    assert torch.isfinite(code).all()
