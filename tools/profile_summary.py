@@ -10,7 +10,7 @@ os.makedirs(out, exist_ok=True)
 
 CLASS = [("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
          ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"),
-         ("layernorm_kernel", "layernorm"), ("add_layernorm_kernel", "layernorm"),
+         ("layernorm_rowtile_kernel", "layernorm_tail(proj,fc2)"), ("layernorm_kernel", "layernorm"),
          ("gemm8_kernel<1,", "gemm_fc1"), ("gemm8_kernel<0,", "gemm_bf16out"), ("gemm8_kernel<2,", "head_gemm1"),
          ("gemm8_kernel<3, 256", "head_gemm2"), ("gemm8_kernel<3, 128", "patch_gemm"),
          ("gemm_bf16_kernel<4", "gemm_resid_tail(proj,fc2)"), ("gemm_bf16_kernel", "gemm_128"),
