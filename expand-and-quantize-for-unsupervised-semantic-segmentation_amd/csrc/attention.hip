@@ -91,23 +91,33 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
     qx.w[0] = 0u; qx.w[1] = 0u; qx.w[2] = 0u; qx.w[3] = 0u;
 
     // ---- K/V staging plan: a tile is 8 pieces of 8 rows per operand; piece p of K and of V is moved
-    // by wave p % NW (with 8 waves: one piece each).  Only the ragged last tile needs its row index
-    // clamped (those keys are masked in the softmax; clamping keeps the V values finite).
+    // by wave p % NW (with 8 waves: one piece each).  The per-lane source pointers of tile 0 are kept
+    // and advanced by a scalar stride; only the ragged last tile needs its row index clamped (those
+    // keys are masked in the softmax; clamping keeps the V values finite).
+    constexpr int NP = kPieces / NW;   // pieces of each operand per wave
+    static_assert(kPieces % NW == 0 && NW % 2 == 0, "piece i of a wave is piece 0 shifted by NW * 8 rows: same chunk swizzle");
+    auto k_chunk = [&](int st_row) { return ((lane & 7) ^ ((st_row >> 1) & 7)) * 8; };
+    auto v_chunk = [&](int st_row) { return ((lane & 7) ^ (((st_row >> 1) & 1) << 2)) * 8; };
+    const int st_row0 = wave * 8 + (lane >> 3);
+    const u16* ksrc = base + (size_t)st_row0 * ld + C + k_chunk(st_row0);
+    const u16* vsrc = base + (size_t)st_row0 * ld + 2 * C + v_chunk(st_row0);
     auto stage = [&](int buf, int t) {
         char* sb = smem + buf * kStage;
 #pragma unroll
-        for (int p0 = 0; p0 < kPieces; p0 += NW) {
-            const int p = p0 + wave;
-            if (p < kPieces) {
+        for (int i = 0; i < NP; ++i) {
+            const int p = i * NW + wave;
+            const size_t step = (size_t)(t * KV + i * NW * 8) * ld;   // scalar
+            const u16* ks = ksrc + step;
+            const u16* vs = vsrc + step;
+            if ((t + 1) * KV > a.N) {
                 const int st_row = p * 8 + (lane >> 3);
-                const int st_kchunk = ((lane & 7) ^ ((st_row >> 1) & 7)) * 8;
-                const int st_vchunk = ((lane & 7) ^ (((st_row >> 1) & 1) << 2)) * 8;
                 int key = t * KV + st_row;
                 if (key > a.N - 1) key = a.N - 1;
-                const u16* src = base + (size_t)key * ld;
-                glds16(src + C + st_kchunk, sb + p * 1024);
-                glds16(src + 2 * C + st_vchunk, sb + kTile + p * 1024);
+                ks = base + (size_t)key * ld + C + k_chunk(st_row);
+                vs = base + (size_t)key * ld + 2 * C + v_chunk(st_row);
             }
+            glds16(ks, sb + p * 1024);
+            glds16(vs, sb + kTile + p * 1024);
         }
     };
 
