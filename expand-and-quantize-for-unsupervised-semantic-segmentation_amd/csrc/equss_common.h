@@ -57,6 +57,23 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 
+// GELU (erf form, torch.nn.GELU's default) with one transcendental:
+//   gelu(x) = x * Phi(x) = max(x, 0) - |x| * (erfc(|x| / sqrt 2) / 2),   erfc(|x| / sqrt 2) / 2 = 2^Q(|x|),
+// Q a degree-5 polynomial fitted to log2 of that tail (smooth and nearly quadratic, unlike erf itself),
+// weighted by the sensitivity |x| 2^Q of the result.  |error| <= 7e-7 absolute over all x (fp32
+// evaluation included), far below the bf16 rounding of the stored result; 5 fma + v_exp + max + fma
+// instead of the rcp + exp + 14 ops of Abramowitz-Stegun 7.1.26 or the ~30 branchy ops of erff.
+// Q's leading coefficient is negative, so large |x| gives 2^Q = 0 without a clamp (x = +-inf gives NaN).
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float a = fabsf(x);
+    float q = fmaf(-0.00047328611253760755f, a, 0.007084404584020376f);
+    q = fmaf(q, a, -0.051827020943164825f);
+    q = fmaf(q, a, -0.45999282598495483f);
+    q = fmaf(q, a, -1.1507877111434937f);
+    q = fmaf(q, a, -1.000037670135498f);
+    return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+}
+
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {  // sum over WIDTH consecutive lanes
 #pragma unroll

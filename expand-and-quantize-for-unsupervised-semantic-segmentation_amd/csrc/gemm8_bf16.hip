@@ -37,21 +37,6 @@ struct Gemm8Args {
 
 constexpr int EPI_RESID_LN = 100;  // internal epilogue id: x += acc + bias; ln = LayerNorm(x)
 
-__device__ __forceinline__ float erf_as(float x) {  // Abramowitz-Stegun 7.1.26, |error| <= 1.5e-7
-    const float ax = fabsf(x);
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    p *= t;
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
-    return copysignf(fmaf(-p, e, 1.0f), x);
-}
-__device__ __forceinline__ float gelu_erf(float x) {
-    return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
-}
-
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(
         (const void __attribute__((address_space(1)))*)gsrc,
@@ -404,7 +389,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         f32x4 v = acc[nt][mt];
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                         if constexpr (EPI == EQUSS_EPI_GELU_BF16) {
-                            v.x = gelu_erf(v.x); v.y = gelu_erf(v.y); v.z = gelu_erf(v.z); v.w = gelu_erf(v.w);
+                            v.x = equss::gelu_erf(v.x); v.y = equss::gelu_erf(v.y); v.z = equss::gelu_erf(v.z); v.w = equss::gelu_erf(v.w);
                         }
                         if constexpr (EPI == EQUSS_EPI_RELU_BF16) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);

@@ -51,6 +51,33 @@ def test_gemm_exact_on_integer_data(epi, shape, native, dev):
         torch.testing.assert_close(got.cpu().float(), _bf(ref).float(), rtol=8e-3, atol=1e-6)
 
 
+@pytest.mark.parametrize("n", [128, 256])
+def test_gelu_epilogue_accuracy(n, native, dev):
+    """The epilogue's GELU against torch's erf form in fp64 over the whole useful range: the
+    pre-activation is x = hi + lo (two bf16 columns against unit weights, exact in fp32), the bf16
+    result is the correctly rounded one up to 1e-6 absolute, and equal to it for nearly all x."""
+    x = torch.cat([torch.linspace(-9.0, 9.0, 8190), torch.tensor([0.0, 1e-3, -1e-3, 20.0, -20.0, 100.0, -100.0,
+                                                                 1e-8, -1e-8, 3e4])])
+    hi = _bf(x)
+    lo = _bf(x - hi.float())
+    xe = hi.double() + lo.double()
+    a = torch.zeros(x.numel(), 64, dtype=torch.bfloat16)
+    a[:, 0], a[:, 1] = hi, lo
+    w = torch.zeros(n, 64, dtype=torch.bfloat16)
+    w[:, :2] = 1.0
+    got = native.gemm_bf16(a.to(dev), w.to(dev), None, 1).cpu()
+    assert torch.equal(got[:, :1].expand(-1, n), got)            # every column saw the same x
+    g = got[:, 0].double()
+    ref = xe * 0.5 * torch.erfc(-xe / math.sqrt(2.0))
+    ulp = torch.exp2(torch.floor(torch.log2(ref.abs().clamp_min(2.0 ** -126))) - 7)   # bf16 spacing at ref
+    err = (g - ref).abs()
+    worst = (err - 0.5 * ulp).max()
+    assert float(worst) <= 1e-6, float(worst)                      # correct rounding + 1e-6 for the formula
+    exact = _bf(ref.float()).double()
+    big = ref.abs() > 1e-2                                         # (the far negative tail is only absolutely accurate)
+    assert float((g[big] == exact[big]).double().mean()) > 0.99
+
+
 def test_gemm_random_and_strided(native, dev):
     g = _rng(5)
     m, n, k = 777, 384, 1536
