@@ -145,71 +145,97 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
     // One key tile: S^T, online softmax, O^T update.
     // `buf` (which staging buffer holds the tile) is a compile-time constant so that every LDS address
     // below is a per-lane base plus an immediate offset.
+    //
+    // Softmax without a per-tile maximum.  VALU instructions do not hide behind MFMAs of other waves on
+    // this part (their times add), so the common path is kept to the arithmetic that cannot be avoided:
+    // exp2 of the score, the running sum, the bf16 conversion.  Any per-query reference works as long
+    // as every key of the query uses the same one between two rescalings, and fp32 / bf16 carry 2^+-100
+    // as well as values near 1, so the reference starts at 0 and is only introduced or raised when a
+    // tile's sum of exponentials leaves [2^-60, 2^60] (or is not finite).  Only then is the tile redone
+    // the classical way: maximum, new reference, rescaling of O and l.  Once a reference exists it rides
+    // on the fifth k step described above.
+    bool have_ref = false;   // wave-uniform
+    constexpr float kBig = 1.152921504606846976e18f, kTiny = 8.673617379884035e-19f;   // 2^60, 2^-60
     auto tile = [&](int t, bool masked, auto buf) {
         const char* kb = smem + decltype(buf)::value * kStage;
         const char* vb = kb + kTile;
-
-        // ---- S^T = K Q^T for the two 32-key tiles --------------------------------------------
         f32x16 s0, s1;
+        // ---- S^T = K Q^T for the two 32-key tiles (+ the reference step), masked on the ragged tile ----
+        auto scores = [&]() {
+            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const bf16x8 ka0 = *reinterpret_cast<const bf16x8*>(kb + k_off[0]);
+            const bf16x8 kc0 = *reinterpret_cast<const bf16x8*>(kb + 32 * 128 + k_off[0]);
+            if (have_ref) {
+                asm volatile("" ::: "memory");   // keep this a real (wave-uniform) branch
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx.v, qx.v, zero, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx.v, qx.v, zero, 0, 0, 0);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[0], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc0, qf[0], s1, 0, 0, 0);
+            } else {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka0, qf[0], zero, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc0, qf[0], zero, 0, 0, 0);
+            }
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { s0[i] = 0.f; s1[i] = 0.f; }
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx.v, qx.v, s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kx.v, qx.v, s1, 0, 0, 0);
+            for (int s = 1; s < 4; ++s) {
+                const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb + k_off[s]);
+                const bf16x8 kc = *reinterpret_cast<const bf16x8*>(kb + 32 * 128 + k_off[s]);
+                s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, qf[s], s1, 0, 0, 0);
+            }
+            // register r of tile u <-> key  t*64 + 32 u + (r&3) + 8 (r>>2) + 4 lh
+            if (masked) {
+                // Only the ragged last tile takes this branch.  The empty asm keeps it a real (wave-uniform)
+                // branch: if-converted, the ~100 compare/select instructions would run for every tile.
+                asm volatile("" ::: "memory");
+                const int kbase = t * KV + 4 * lh;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const bf16x8 ka = *reinterpret_cast<const bf16x8*>(kb + k_off[s]);
-            const bf16x8 kc = *reinterpret_cast<const bf16x8*>(kb + 32 * 128 + k_off[s]);
-            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[s], s0, 0, 0, 0);
-            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kc, qf[s], s1, 0, 0, 0);
-        }
-        // register r of tile u <-> key  t*64 + 32 u + (r&3) + 8 (r>>2) + 4 lh
-        if (masked) {
-            // Only the ragged last tile takes this branch.  The empty asm keeps it a real (wave-uniform)
-            // branch: if-converted, the ~100 compare/select instructions would run for every tile.
-            asm volatile("" ::: "memory");
-            const int kbase = t * KV + 4 * lh;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + (r & 3) + 8 * (r >> 2);
+                    if (key >= a.N) s0[r] = -__builtin_inff();
+                    if (key + 32 >= a.N) s1[r] = -__builtin_inff();
+                }
+            }
+        };
+        float psum;
+        auto exponentials = [&]() {
+            psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kbase + (r & 3) + 8 * (r >> 2);
-                if (key >= a.N) s0[r] = -__builtin_inff();
-                if (key + 32 >= a.N) s1[r] = -__builtin_inff();
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+                psum += s0[r] + s1[r];
             }
-        }
-        // ---- online softmax ------------------------------------------------------------------
-        float mloc = s0[0];
+        };
+        scores();
+        exponentials();
+        const bool out_of_range = !(psum < kBig) || (t == 0 && !(psum > kTiny));
+        if (__builtin_amdgcn_ballot_w64(out_of_range) != 0) {
+            asm volatile("" ::: "memory");   // keep this a real branch: it is rare
+            scores();
+            float mloc = s0[0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s0[r]);
+            for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s0[r]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s1[r]);
-        mloc = fmaxf(mloc, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xhalf, __builtin_bit_cast(int, mloc))));
-        // Lazy rescaling: the reference follows the true maximum only when that exceeds it by more than 8
-        // (p then stays <= 256, harmless in fp32 / bf16), so on most tiles O is not touched and the scores
-        // need no subtraction at all.  The choice is per wave; the first tile always sets the reference.
-        if (t == 0 || __builtin_amdgcn_ballot_w64(mloc > 8.0f) != 0) {
-            asm volatile("" ::: "memory");   // keep this a real branch
-            const float grow = fmaxf(mloc, t == 0 ? -__builtin_inff() : 0.f);   // never lower the reference later
-            // new reference = the maximum rounded UP to bf16: every score then comes out <= 0 and exp2 cannot
-            // overflow however large the logits are
+            for (int r = 0; r < 16; ++r) mloc = fmaxf(mloc, s1[r]);
+            mloc = fmaxf(mloc, __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(xhalf, __builtin_bit_cast(int, mloc))));
+            // The first tile may set any reference (O and l are still zero); later ones only raise it.
+            const float grow = fmaxf(mloc, t == 0 ? -__builtin_inff() : 0.f);
+            // new reference = the maximum rounded UP to bf16: every score of this tile then comes out <= 0
             const float target = m_run + (grow > -__builtin_inff() ? grow : 0.f);
             u16 mb = equss::f2bf(target);
             if (equss::bf2f(mb) < target) mb = (u16)(target > 0.f ? mb + 1 : mb - 1);
             const float m_new = equss::bf2f(mb);
-            const float shift = m_new - m_run;         // >= 0 except possibly on the first tile
-            const float alpha = __builtin_amdgcn_exp2f(-shift);
+            const float shift = m_new - m_run;
+            const float alpha = t == 0 ? 0.f : __builtin_amdgcn_exp2f(-shift);
             m_run = m_new;
             qx.w[0] = lh == 0 ? (uint32_t)(mb ^ 0x8000u) : 0u;   // -m_run as bf16 in the first slot
+            have_ref = true;
             l_run *= alpha;
 #pragma unroll
             for (int i = 0; i < 16; ++i) { o0[i] *= alpha; o1[i] *= alpha; }
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s0[r] -= shift; s1[r] -= shift; }
-        }
-        float psum = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r]);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-            psum += s0[r] + s1[r];
+            exponentials();
         }
         l_run += psum;
 

@@ -64,14 +64,20 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
 // evaluation included), far below the bf16 rounding of the stored result; 5 fma + v_exp + max + fma
 // instead of the rcp + exp + 14 ops of Abramowitz-Stegun 7.1.26 or the ~30 branchy ops of erff.
 // Q's leading coefficient is negative, so large |x| gives 2^Q = 0 without a clamp (x = +-inf gives NaN).
-__device__ __forceinline__ float gelu_erf(float x) {
-    const float a = fabsf(x);
-    float q = fmaf(-0.00047328611253760755f, a, 0.007084404584020376f);
-    q = fmaf(q, a, -0.051827020943164825f);
-    q = fmaf(q, a, -0.45999282598495483f);
-    q = fmaf(q, a, -1.1507877111434937f);
-    q = fmaf(q, a, -1.000037670135498f);
-    return fmaf(-a, __builtin_amdgcn_exp2f(q), fmaxf(x, 0.f));
+// Two values at a time: the packed fp32 fma issues once for both (|x| = 2 max(x, 0) - x is exact and
+// saves the two sign-bit masks; there is no packed max or exp).
+typedef float gelu_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
+    const gelu_f32x2 relu = {fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
+    const gelu_f32x2 a = __builtin_elementwise_fma(gelu_f32x2{2.f, 2.f}, relu, -x);
+    gelu_f32x2 q = __builtin_elementwise_fma(gelu_f32x2{-0.00047328611253760755f, -0.00047328611253760755f}, a,
+                                             gelu_f32x2{0.007084404584020376f, 0.007084404584020376f});
+    q = __builtin_elementwise_fma(q, a, gelu_f32x2{-0.051827020943164825f, -0.051827020943164825f});
+    q = __builtin_elementwise_fma(q, a, gelu_f32x2{-0.45999282598495483f, -0.45999282598495483f});
+    q = __builtin_elementwise_fma(q, a, gelu_f32x2{-1.1507877111434937f, -1.1507877111434937f});
+    q = __builtin_elementwise_fma(q, a, gelu_f32x2{-1.000037670135498f, -1.000037670135498f});
+    const gelu_f32x2 e = {__builtin_amdgcn_exp2f(q.x), __builtin_amdgcn_exp2f(q.y)};
+    return __builtin_elementwise_fma(-a, e, relu);
 }
 
 template <int WIDTH>

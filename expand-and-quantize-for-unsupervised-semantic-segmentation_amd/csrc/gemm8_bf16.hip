@@ -389,7 +389,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         f32x4 v = acc[nt][mt];
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
                         if constexpr (EPI == EQUSS_EPI_GELU_BF16) {
-                            v.x = equss::gelu_erf(v.x); v.y = equss::gelu_erf(v.y); v.z = equss::gelu_erf(v.z); v.w = equss::gelu_erf(v.w);
+                            const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
+                            const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
+                            v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
                         }
                         if constexpr (EPI == EQUSS_EPI_RELU_BF16) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
@@ -460,6 +462,10 @@ int launch(Gemm8Args& g, hipStream_t s) {
     if (g_stages == 6 && g.N % 192 == 0) {   // two 4-wave workgroups per CU, 128 x 192 tiles
         g.ntn = g.N / 192;
         return launch_inst<EPI, 128, 192, 2, 2, 32, 3>(g, s);
+    }
+    if (g_stages == 7 && g.N % 128 == 0) {   // two 4-wave workgroups per CU, 256 x 128 tiles
+        g.ntn = g.N / 128;
+        return launch_inst<EPI, 256, 128, 2, 2, 32, 3>(g, s);
     }
     if (g.N % 384 == 0 && !(g_prefer256 && g.N % 256 == 0)) {
         g.ntn = g.N / 384;

@@ -56,7 +56,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], 
             f32x4 v = acc[nt][mt];
             v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
             if constexpr (EPI == EQUSS_EPI_GELU_BF16) {
-                v.x = equss::gelu_erf(v.x); v.y = equss::gelu_erf(v.y); v.z = equss::gelu_erf(v.z); v.w = equss::gelu_erf(v.w);
+                const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
+                            const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
+                            v.x = g0.x; v.y = g0.y; v.z = g1.x; v.w = g1.y;
             }
             if constexpr (EPI == EQUSS_EPI_RELU_BF16) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);

@@ -8,10 +8,10 @@ nat = pkg.native
 lib = nat.load_library()
 dev = torch.device("cuda", 0)
 M = 64 * 1601
-SHAPES = [("qkv", M, 1152, 384, 0), ("proj", M, 384, 384, 0), ("fc1", M, 1536, 384, 1), ("fc2", M, 384, 1536, 0),
+SHAPES = [("qkv", M, 1152, 384, 0), ("proj", M, 384, 384, 0), ("fc1", M, 1536, 384, 1), ("fc1_nogelu", M, 1536, 384, 0), ("fc2", M, 384, 1536, 0),
           ("head2", 64 * 1600, 1024, 768, 3)]
 variants = [int(v) for v in sys.argv[1:]] or [0]
-STAGES = {62: 2 + 8, 63: 3 + 8, 64: 4 + 8, 32: 2, 33: 3, 34: 4, 205: 5 + 8, 206: 6 + 8}
+STAGES = {62: 2 + 8, 63: 3 + 8, 64: 4 + 8, 32: 2, 33: 3, 34: 4, 205: 5 + 8, 206: 6 + 8, 207: 7 + 8}
 torch.manual_seed(0)
 for name, m, n, k, epi in SHAPES:
     a = (torch.randn(m, k, device=dev)).to(torch.bfloat16)
