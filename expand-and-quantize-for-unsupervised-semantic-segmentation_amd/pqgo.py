@@ -34,8 +34,55 @@ def _unit(t):
     return F.normalize(t, dim=1, eps=1e-10)
 
 
-def _grid_sample(t, coords):
-    return F.grid_sample(t, coords.permute(0, 2, 1, 3), padding_mode="border", align_corners=True)
+class _BilinearGather(torch.autograd.Function):
+    """out[p] = sum_k wgt[p, k] * rows[idx[p, k]]: the four-neighbour gather behind the point sampling
+    below.  The backward scatters into ONE dense gradient (a zero fill and four index_add_), where
+    autograd through grid_sample or through advanced indexing would build a dense gradient per call."""
+
+    @staticmethod
+    def forward(ctx, rows, idx, wgt):
+        out = rows[idx[:, 0]] * wgt[:, 0:1]
+        for k in range(1, 4):
+            out.addcmul_(rows[idx[:, k]], wgt[:, k:k + 1])
+        ctx.save_for_backward(idx, wgt)
+        ctx.rows_shape = rows.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        idx, wgt = ctx.saved_tensors
+        grad = g.new_zeros(ctx.rows_shape)
+        for k in range(4):
+            grad.index_add_(0, idx[:, k], g * wgt[:, k:k + 1])
+        return grad, None, None
+
+
+def _sample_points(t, coords, batch_index=None):
+    """The reference's ``sample(t, coords)`` (model/loss.py:647-648: grid_sample, bilinear, border
+    padding, align_corners=True) for S coordinate sets at once.
+
+    t (B, C, h, w); coords (S, B, n, n, 2) in [-1, 1]; batch_index (S, B) long or None: set s samples
+    image batch_index[s, b] (the reference's ``t[perm]``) without copying t.  Returns (S, B, C, n, n).
+    A sample point touches four tokens, so this is a row gather from the token-major tensor (a free
+    view for the tensors of the training pass) instead of a kernel that walks, and in the backward
+    zero-fills and atomically updates, the whole (B, C, h, w) map once per coordinate set."""
+    s_, b, n1, n2, _ = coords.shape
+    _, c, h, w = t.shape
+    rows = _rows_of(t)
+    g = coords.permute(0, 1, 3, 2, 4)                      # sample(): grid = coords.permute(0, 2, 1, 3)
+    ix = (((g[..., 0] + 1) / 2) * (w - 1)).clamp(0, w - 1)
+    iy = (((g[..., 1] + 1) / 2) * (h - 1)).clamp(0, h - 1)
+    x0, y0 = ix.floor(), iy.floor()
+    x1, y1 = x0 + 1, y0 + 1
+    wgt = torch.stack(((x1 - ix) * (y1 - iy), (ix - x0) * (y1 - iy), (x1 - ix) * (iy - y0), (ix - x0) * (iy - y0)), dim=-1)
+    x0l, y0l = x0.long(), y0.long()
+    x1l, y1l = (x0l + 1).clamp_(max=w - 1), (y0l + 1).clamp_(max=h - 1)   # weight is 0 where the neighbour is outside
+    if batch_index is None:
+        batch_index = torch.arange(b, device=t.device).expand(s_, b)
+    base = (batch_index * (h * w)).reshape(s_, b, 1, 1)
+    idx = torch.stack((base + y0l * w + x0l, base + y0l * w + x1l, base + y1l * w + x0l, base + y1l * w + x1l), dim=-1)
+    out = _BilinearGather.apply(rows, idx.reshape(-1, 4), wgt.reshape(-1, 4).to(rows.dtype))
+    return out.reshape(s_, b, n2, n1, c).permute(0, 1, 4, 2, 3)
 
 
 def _derangement_like(size: int, device):
@@ -67,22 +114,69 @@ class STEGOLoss(nn.Module):
 
     def forward(self, orig_feats, orig_feats_pos, orig_code, orig_code_pos):
         n = self.cfg["feature_samples"]
-        shape = [orig_feats.shape[0], n, n, 2]
-        coords1 = torch.rand(shape, device=orig_feats.device) * 2 - 1
-        coords2 = torch.rand(shape, device=orig_feats.device) * 2 - 1
-        feats, code = _grid_sample(orig_feats, coords1), _grid_sample(orig_code, coords1)
-        feats_pos, code_pos = _grid_sample(orig_feats_pos, coords2), _grid_sample(orig_code_pos, coords2)
+        b = orig_feats.shape[0]
+        dev = orig_feats.device
+        shape = [b, n, n, 2]
+        coords1 = torch.rand(shape, device=dev) * 2 - 1
+        coords2 = torch.rand(shape, device=dev) * 2 - 1
+        # same random stream as the reference (loss.py:694-731: coords1, coords2, then one permutation per
+        # negative); all point sets of one tensor are then gathered in a single call
+        perms = [_derangement_like(b, dev) for _ in range(self.cfg["neg_samples"])]
+        own = torch.arange(b, device=dev)
+        coords = torch.stack([coords1] + [coords2] * len(perms))
+        which = torch.stack([own] + perms)
+        with torch.no_grad():
+            feats_all = _sample_points(orig_feats, coords, which)
+            feats_pos = _sample_points(orig_feats_pos, coords2[None])[0]
+        code_all = _sample_points(orig_code, coords, which)
+        code_pos = _sample_points(orig_code_pos, coords2[None])[0]
+        feats, code = feats_all[0], code_all[0]
         pos_intra, _ = self.helper(feats, feats, code, code, self.cfg["pos_intra_shift"])
         pos_inter, _ = self.helper(feats, feats_pos, code, code_pos, self.cfg["pos_inter_shift"])
         neg = []
-        for _ in range(self.cfg["neg_samples"]):
-            perm = _derangement_like(orig_feats.shape[0], orig_feats.device)
-            feats_neg, code_neg = _grid_sample(orig_feats[perm], coords2), _grid_sample(orig_code[perm], coords2)
-            neg_loss, _ = self.helper(feats, feats_neg, code, code_neg, self.cfg["neg_inter_shift"])
+        for k in range(len(perms)):
+            neg_loss, _ = self.helper(feats, feats_all[1 + k], code, code_all[1 + k], self.cfg["neg_inter_shift"])
             neg.append(neg_loss)
         neg = torch.cat(neg, dim=0)
         return (self.cfg["pos_intra_weight"] * pos_intra.mean() + self.cfg["pos_inter_weight"] * pos_inter.mean() +
                 self.cfg["neg_inter_weight"] * neg.mean())
+
+
+# ------------------------------------------------------------------------------------------------
+# Expansion head in the training pass
+# ------------------------------------------------------------------------------------------------
+class _HeadFunction(torch.autograd.Function):
+    """cluster1(f) + cluster2(f) on token-major rows: forward through the same HIP head GEMMs as the
+    eval path (bf16 operands, fp32 accumulation and output), backward as bf16 GEMMs with fp32
+    accumulation -- the precision class of the reference's training pass, which runs these
+    convolutions under fp16 autocast (train.py:80).  The frozen backbone needs no input gradient.
+    The HIP forward leaves [f | relu(W2a f + b2a)] behind in bf16, which is what the backward needs."""
+
+    @staticmethod
+    def forward(ctx, rows, w1, b1, w2a, b2a, w2b, b2b):
+        n, c = rows.shape
+        d = w1.shape[0]
+        fh = torch.empty((n, 2 * c), dtype=torch.bfloat16, device=rows.device)
+        fh[:, :c] = rows
+        w_cat = torch.cat((w1.reshape(d, c), w2b.reshape(d, c)), dim=1).to(torch.bfloat16).contiguous()
+        code = native.expand_head(fh, w2a.reshape(c, c).to(torch.bfloat16).contiguous(), b2a.float().contiguous(),
+                                  w_cat, (b1 + b2b).float().contiguous(), d)
+        ctx.save_for_backward(fh, w_cat)
+        ctx.shapes = (w1.shape, w2a.shape, w2b.shape)
+        return code
+
+    @staticmethod
+    def backward(ctx, g):
+        fh, w_cat = ctx.saved_tensors
+        c = fh.shape[1] // 2
+        s1, s2a, s2b = ctx.shapes
+        g_bf = g.to(torch.bfloat16)
+        dw_cat = torch.mm(g_bf.t(), fh).float()                  # (D, 2C) = [dW1 | dW2b]
+        d_pre = torch.mm(g_bf, w_cat[:, c:]) * (fh[:, c:] > 0)   # through the ReLU
+        dw2a = torch.mm(d_pre.t(), fh[:, :c]).float()
+        db = g.sum(0)
+        return (None, dw_cat[:, :c].reshape(s1), db, dw2a.reshape(s2a), d_pre.float().sum(0),
+                dw_cat[:, c:].reshape(s2b), db)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -364,15 +458,11 @@ class DIONPQGO(nn.Module):
     # -- expansion head weights for the HIP GEMMs ---------------------------------------------------
     def _head_autograd(self, feat: torch.Tensor) -> torch.Tensor:
         """cluster1(f) + cluster2(f) (dino_pqgo.py:104-112,:127-128) for the training pass: the 1x1
-        convolutions are per-token linears, evaluated as three GEMMs on token-major rows (the feature
-        map is a channels-first view of token-major memory, a layout convolution libraries only cover
-        with slow generic kernels)."""
+        convolutions are per-token linears on token-major rows (the feature map is a channels-first
+        view of token-major memory); see _HeadFunction."""
         b, c, h, w = feat.shape
-        rows = _rows_of(feat)
         w1, w2a, w2b = self.cluster1[0], self.cluster2[0], self.cluster2[2]
-        code = F.linear(rows, w1.weight.view(w1.out_channels, c), w1.bias)
-        hid = F.relu(F.linear(rows, w2a.weight.view(w2a.out_channels, c), w2a.bias))
-        code = code + F.linear(hid, w2b.weight.view(w2b.out_channels, w2b.in_channels), w2b.bias)
+        code = _HeadFunction.apply(_rows_of(feat), w1.weight, w1.bias, w2a.weight, w2a.bias, w2b.weight, w2b.bias)
         return _nchw_of(code, b, h, w)
 
     def _head_weights(self):

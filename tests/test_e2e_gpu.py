@@ -178,3 +178,30 @@ def test_bcfg_vit_base_pq16x512(pkg, oracle, golden, dev):
     want_idx, gap = oracle.pq_top2_gap([b.cpu() for b in books], rows(code).cpu().contiguous(), "l2")
     assert_index_parity(z_index.reshape(16, -1).cpu().numpy(), want_idx.numpy(), gap.numpy(), "G11 own code")
     assert abs(float(outputs["vq-loss"]) - float(g["vq_loss"])) < 2e-2 * float(g["vq_loss"])
+
+
+def test_training_head_matches_fp32_autograd(pkg, dev):
+    """The training pass's expansion head (HIP forward, bf16 GEMM backward) against fp32 autograd
+    through three F.linear (dino_pqgo.py:104-112): code and every parameter gradient."""
+    import torch.nn.functional as F
+    torch.manual_seed(5)
+    n, c, d = 1000, 384, 1024
+    rows = torch.randn(n, c, device=dev)
+    ps = [torch.randn(d, c, 1, 1, device=dev) * 0.05, torch.randn(d, device=dev) * 0.1,
+          torch.randn(c, c, 1, 1, device=dev) * 0.05, torch.randn(c, device=dev) * 0.1,
+          torch.randn(d, c, 1, 1, device=dev) * 0.05, torch.randn(d, device=dev) * 0.1]
+    ps = [p.requires_grad_(True) for p in ps]
+    g_out = torch.randn(n, d, device=dev)
+    code = pkg.pqgo._HeadFunction.apply(rows, *ps)
+    got = torch.autograd.grad((code * g_out).sum(), ps)
+    w1, b1, w2a, b2a, w2b, b2b = ps
+    ref_code = F.linear(rows, w1.view(d, c), b1) + F.linear(F.relu(F.linear(rows, w2a.view(c, c), b2a)), w2b.view(d, c), b2b)
+    ref = torch.autograd.grad((ref_code * g_out).sum(), ps)
+    assert float((code - ref_code).norm() / ref_code.norm()) < 1e-2
+    errs = {name: float((a - b).norm() / b.norm()) for name, a, b in zip(("w1", "b1", "w2a", "b2a", "w2b", "b2b"), got, ref)}
+    print("head gradient rel-L2 errors:", errs)
+    for name, a, b in zip(errs, got, ref):
+        assert a.shape == b.shape, name
+    # (w2a, b2a: the ReLU mask is the bf16 forward's; the ~0.1 % of units close enough to zero to flip
+    # against the fp32 forward give a few percent in the norm)
+    assert max(errs.values()) < 5e-2, errs

@@ -130,3 +130,29 @@ def test_bench_work_model_matches_survey_numbers():
     assert abs((w["head_gemm1"]["flops"] + w["head_gemm2"]["flops"]) / 1e9 - 2.99) < 0.01
     assert abs(w["pq_assign"]["flops"] / 1e9 - 0.839) < 0.001
     assert abs(w["pq_assign"]["bytes"] / 1e6 - 13.21) < 0.01       # MB per image
+
+
+def test_point_sampling_matches_grid_sample(pkg):
+    """The four-neighbour gather of the STEGO loss against F.grid_sample (loss.py:647-648), values and
+    gradients, including coordinates on the border and permuted images."""
+    import torch.nn.functional as F
+    pq = pkg.pqgo
+    torch.manual_seed(3)
+    b, c, h, w, n = 3, 5, 6, 7, 4
+    t = torch.randn(b, h * w, c).requires_grad_(True)
+    tm = t.reshape(b, h, w, c).permute(0, 3, 1, 2)                      # channels-first view of token-major rows
+    coords = torch.rand(2, b, n, n, 2) * 2 - 1
+    coords[0, 0, 0, 0] = torch.tensor([1.0, -1.0])
+    coords[0, 0, 0, 1] = torch.tensor([-1.0, 1.0])
+    coords[1, 1, 2, 2] = torch.tensor([1.0, 1.0])
+    perm = torch.tensor([2, 0, 1])
+    which = torch.stack([torch.arange(b), perm])
+    got = pq._sample_points(tm, coords, which)
+    ref0 = F.grid_sample(tm, coords[0].permute(0, 2, 1, 3), padding_mode="border", align_corners=True)
+    ref1 = F.grid_sample(tm[perm], coords[1].permute(0, 2, 1, 3), padding_mode="border", align_corners=True)
+    torch.testing.assert_close(got[0], ref0, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(got[1], ref1, rtol=1e-5, atol=1e-6)
+    wgt = torch.randn_like(got)
+    (g_got,) = torch.autograd.grad((got * wgt).sum(), t)
+    (g_ref,) = torch.autograd.grad((ref0 * wgt[0]).sum() + (ref1 * wgt[1]).sum(), t)
+    torch.testing.assert_close(g_got, g_ref, rtol=1e-5, atol=1e-6)

@@ -11,7 +11,7 @@ shapes = {"qkv": (M, 1152, 384, 0), "proj": (M, 384, 384, 4), "fc1": (M, 1536, 3
           "head2": (64 * 1600, 1024, 768, 3)}
 name, variant = sys.argv[1], int(sys.argv[2])
 m, n, k, epi = shapes[name]
-STAGES = {32: 2, 33: 3, 34: 4, 42: 2 + 16, 44: 4 + 16}
+STAGES = {62: 2 + 8, 63: 3 + 8, 64: 4 + 8, 32: 2, 33: 3, 34: 4, 205: 5 + 8, 206: 6 + 8, 207: 7 + 8}
 if variant in STAGES:
     lib.equss_dev_gemm_variant(ctypes.c_int(3)); lib.equss_dev_gemm_stages(ctypes.c_int(STAGES[variant]))
 else:

@@ -3,6 +3,7 @@
 // build: hipcc --offload-arch=gfx950 -O3 -o issue_rates issue_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -13,7 +14,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 constexpr int kIters = KITERS;
 
 template <int MODE_EVEN, int MODE_ODD>   // 0 exp, 1 fma, 2 pk_fma, 3 mfma, 4 mfma+exp same wave, 5 idle, 6 max3, 7 cvt_pk
-__global__ __launch_bounds__(1024) void k(float* out, float seed) {
+__global__ __launch_bounds__(1024) void k(float* out, float seed, const bf16x8* rnd = nullptr) {
     const int wave = threadIdx.x >> 6;
     const int mode = ((wave >> 2) & 1) ? MODE_ODD : MODE_EVEN;   // waves 0-3 / 4-7 / ...: both kinds land on every SIMD
     float v[16];
@@ -65,6 +66,18 @@ __global__ __launch_bounds__(1024) void k(float* out, float seed) {
                 asm volatile("v_exp_f32 %0, %0" : "+v"(v[2 * i + 1]));
             }
         }
+    } else if (mode == 8) {
+        // operands with realistic bit activity: 8 distinct random fragments per lane, rotated
+        bf16x8 ra[4], rb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = rnd[(threadIdx.x * 8 + i) & 4095]; rb[i] = rnd[(threadIdx.x * 8 + 4 + i) & 4095]; }
+        for (int it = 0; it < kIters; ++it) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[i & 3], rb[(i + 1) & 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ra[(i + 2) & 3], rb[i & 3], acc1, 0, 0, 0);
+            }
+        }
     } else if (mode == 6) {
         for (int it = 0; it < kIters; ++it) {
 #pragma unroll
@@ -83,13 +96,13 @@ __global__ __launch_bounds__(1024) void k(float* out, float seed) {
 }
 
 template <int E, int O>
-void run(const char* name, float* out, int instr_even, int instr_odd) {
+void run(const char* name, float* out, int instr_even, int instr_odd, const bf16x8* rnd = nullptr) {
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<E, O>), dim3(256), dim3(1024), 0, 0, out, 1.0f);
+    hipLaunchKernelGGL((k<E, O>), dim3(256), dim3(1024), 0, 0, out, 1.0f, rnd);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<E, O>), dim3(256), dim3(1024), 0, 0, out, 1.0f);
+    for (int r = 0; r < 5; ++r) hipLaunchKernelGGL((k<E, O>), dim3(256), dim3(1024), 0, 0, out, 1.0f, rnd);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
@@ -102,6 +115,15 @@ void run(const char* name, float* out, int instr_even, int instr_odd) {
 
 int main() {
     float* out; hipMalloc(&out, 4096);
+    unsigned short* h = (unsigned short*)malloc(4096 * 16);
+    unsigned st = 12345u;
+    for (int i = 0; i < 4096 * 8; ++i) {   // random sign, exponent near 1, random mantissa
+        st = st * 1664525u + 1013904223u;
+        h[i] = (unsigned short)(((st >> 16) & 0x80ffu) | (0x3f00u + ((st >> 9) & 0x0100u)));
+    }
+    bf16x8* rnd; hipMalloc(&rnd, 4096 * 16); hipMemcpy(rnd, h, 4096 * 16, hipMemcpyHostToDevice);
+    run<8, 8>("mfma random operands (all)", out, 16, 16, rnd);
+    run<8, 5>("mfma random operands | idle", out, 16, 0, rnd);
     run<0, 0>("exp | exp", out, 16, 16);
     run<1, 1>("fma | fma", out, 16, 16);
     run<2, 2>("pk_fma | pk_fma", out, 16, 16);
