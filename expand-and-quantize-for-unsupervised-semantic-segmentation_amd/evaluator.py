@@ -114,7 +114,8 @@ class UnSegEvaluator(nn.Module):
             probes, bias = native.pack_probes(lp.weight, lp.bias, self.cluster_probe.clusters)
             _lin, _clu, _losses, norms = native.probe_eval(rows, probes, bias, label.long(), b, h, w, self.num_classes,
                                                            self.cluster_probe.n_classes, want_norm=True)
-        maps = lambda t: t.reshape(b, h, w, -1).permute(0, 3, 1, 2)   # noqa: E731
+        # (contiguous NCHW: the channels-last bilinear backward is ~5x slower, and these maps are tiny)
+        maps = lambda t: t.reshape(b, h, w, -1).permute(0, 3, 1, 2).contiguous()   # noqa: E731
         linear_logits = up(maps(F.linear(rows, lp.weight.view(lp.out_channels, lp.in_channels), lp.bias)))
         inner = up(maps(F.linear(rows, F.normalize(self.cluster_probe.clusters, dim=1)))) / norms.unsqueeze(1)
         top = inner.max(dim=1)
