@@ -420,12 +420,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
 
 int g_stages = 2;
 int g_prefer256 = 1;  // 256 x 256 tiles when N allows (131 flop/B instead of 96)
+int g_cu_share = 256;   // CUs one launch may occupy (developer knob: two streams sharing the device)
 
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
 int launch_inst(const Gemm8Args& g, hipStream_t s) {
     const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
     constexpr int kThreads = WM * WN * 64;
-    constexpr int resident = WM * WN == 8 ? 256 : 512;  // one 8-wave or two 4-wave workgroups per CU
+    const int resident = (WM * WN == 8 ? 1 : 2) * g_cu_share;  // one 8-wave or two 4-wave workgroups per CU
     const int grid = ntiles < resident ? ntiles : resident;
     constexpr int ring = S * (BM + BN) * BK * 2;
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
@@ -521,4 +522,5 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
 
 }  // namespace equss
 
+extern "C" void equss_dev_gemm_cu_share(int n) { g_cu_share = n > 0 && n <= 256 ? n : 256; }
 extern "C" void equss_dev_gemm_stages(int s) { g_stages = s & 7; g_prefer256 = (s >> 3) & 1; }  // tuning knob, not part of the ABI

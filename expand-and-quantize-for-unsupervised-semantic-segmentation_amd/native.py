@@ -142,8 +142,9 @@ _ws_cache = {}
 
 
 def _workspace(device, nbytes, tag):
-    """A per-(device, tag) scratch tensor that only grows; 256-byte aligned by the caching allocator."""
-    key = (device, tag)
+    """A per-(device, stream, tag) scratch tensor that only grows; 256-byte aligned by the caching
+    allocator.  Keyed by the current stream as well: launches on different streams may overlap."""
+    key = (device, tag, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
@@ -172,9 +173,10 @@ def profile_read(reset=True):
 # ------------------------------------------------------------------------------------------------
 # Product quantisation
 # ------------------------------------------------------------------------------------------------
-def pq_assign(code_rows, codebooks, normalize="l2", gather_normalized=False, want_zq=True, want_loss=True):
+def pq_assign(code_rows, codebooks, normalize="l2", gather_normalized=False, want_zq=True, want_loss=True, zq_out=None):
     """code_rows (rows, num_pq*d) fp32 (row stride may exceed the width), codebooks (num_pq, K, d) fp32.
-    Returns idx (num_pq, rows) int64, zq (rows, num_pq*d) fp32 or None, loss_sum (num_pq,) fp32 or None."""
+    Returns idx (num_pq, rows) int64, zq (rows, num_pq*d) fp32 or None, loss_sum (num_pq,) fp32 or None.
+    zq_out: optional contiguous (rows, num_pq*d) fp32 destination for zq (e.g. a row range of a larger buffer)."""
     lib = load_library()
     _need_cuda(code_rows, codebooks)
     if code_rows.dtype != torch.float32 or codebooks.dtype != torch.float32:
@@ -190,7 +192,12 @@ def pq_assign(code_rows, codebooks, normalize="l2", gather_normalized=False, wan
     codebooks = codebooks.contiguous()
     dev = code_rows.device
     idx = torch.empty((num_pq, rows), dtype=torch.int64, device=dev)
-    zq = torch.empty((rows, width), dtype=torch.float32, device=dev) if want_zq else None
+    if zq_out is not None:
+        if zq_out.shape != (rows, width) or zq_out.dtype != torch.float32 or not zq_out.is_contiguous():
+            raise ValueError("zq_out must be a contiguous float32 (rows, num_pq*d) tensor")
+        zq = zq_out
+    else:
+        zq = torch.empty((rows, width), dtype=torch.float32, device=dev) if want_zq else None
     loss = torch.empty((num_pq,), dtype=torch.float32, device=dev) if want_loss else None
     if rows == 0:
         if loss is not None:
@@ -336,12 +343,18 @@ def vit_forward(handle, img, pos, feat_bf16=None, ld_feat=None, want_f32=False):
     return (feat_bf16, feat_f32) if want_f32 else feat_bf16
 
 
-def expand_head(fh, w2a, b2a, w_cat, b_cat, out_dim):
-    """fh (rows, 2C) bf16 with the features in columns [0,C): returns code (rows, D) fp32."""
+def expand_head(fh, w2a, b2a, w_cat, b_cat, out_dim, out=None):
+    """fh (rows, 2C) bf16 with the features in columns [0,C): returns code (rows, D) fp32 (written into
+    ``out`` when given: a contiguous (rows, D) fp32 tensor, e.g. a row range of a larger buffer)."""
     lib = load_library()
     _need_cuda(fh, w2a, b2a, w_cat, b_cat)
     rows, c2 = fh.shape
-    code = torch.empty((rows, out_dim), dtype=torch.float32, device=fh.device)
+    if out is not None:
+        if out.shape != (rows, out_dim) or out.dtype != torch.float32 or not out.is_contiguous():
+            raise ValueError("out must be a contiguous float32 (rows, D) tensor")
+        code = out
+    else:
+        code = torch.empty((rows, out_dim), dtype=torch.float32, device=fh.device)
     rc = lib.equss_expand_head(_ptr(fh), _ptr(w2a), _ptr(b2a), _ptr(w_cat), _ptr(b_cat), _ptr(code), rows, c2 // 2,
                                out_dim, _stream(fh))
     _check(rc, "equss_expand_head")

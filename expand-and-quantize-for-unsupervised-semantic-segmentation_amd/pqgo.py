@@ -454,6 +454,9 @@ class DIONPQGO(nn.Module):
         self.stego_loss = STEGOLoss(cfg=self.cfg_loss["stego"])
         self._head = None
         self._head_key = None
+        # eval forward: image ranges of a batch run on this many HIP streams (1 = everything on the caller's)
+        self.eval_streams = 2
+        self._streams = None
 
     # -- expansion head weights for the HIP GEMMs ---------------------------------------------------
     def _head_autograd(self, feat: torch.Tensor) -> torch.Tensor:
@@ -492,12 +495,69 @@ class DIONPQGO(nn.Module):
         code = native.expand_head(fh, hw["w2a"], hw["b2a"], hw["w_cat"], hw["b_cat"], self.hidden_dim)
         return code, feat32
 
+    @torch.no_grad()
+    def _forward_eval_streams(self, img):
+        """The eval forward with the batch cut into ``eval_streams`` image ranges, each run ViT -> head ->
+        PQ on its own HIP stream into row ranges of shared output buffers.  Images are independent and
+        every kernel gives an image the same bits whatever the batch around it, so the result equals the
+        single-stream one (the loss sums are added in a different order); what changes is that one
+        range's store-bound epilogues and partly filled last rounds of workgroups overlap the other
+        range's compute.  The caller's stream waits for all ranges before this returns."""
+        b, _, h, w = img.shape
+        p = self.extractor.patch_size
+        gh, gw = h // p, w // p
+        n, c, dim = gh * gw, self.feat_dim, self.hidden_dim
+        dev = img.device
+        pqw = self.vq_blocks[0]
+        q0 = pqw.quantizers[0]
+        if pqw.pq_dim not in _PQ_DIMS:
+            raise ValueError(f"sub-space dim {pqw.pq_dim} is not supported by the HIP assign kernel {_PQ_DIMS}")
+        books = pqw.stacked_codebooks()
+        hw = self._head_weights()
+        img = img.detach().to(torch.float32).contiguous()
+        self.extractor.backbone._pos_for(h, w)     # cached tables and weight sets are built on the caller's stream
+        self.extractor.backbone.device_handle()
+        fh = torch.empty((b * n, 2 * c), dtype=torch.bfloat16, device=dev)
+        code = torch.empty((b * n, dim), dtype=torch.float32, device=dev)
+        zq = torch.empty_like(code)
+        k = self.eval_streams
+        if self._streams is None or len(self._streams) != k or self._streams[0].device != dev:
+            self._streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        main = torch.cuda.current_stream(dev)
+        start = torch.cuda.Event()
+        start.record(main)
+        idx_parts, loss_parts = [], []
+        for i, s in enumerate(self._streams):
+            lo, hi = b * i // k, b * (i + 1) // k
+            r0, r1 = lo * n, hi * n
+            s.wait_event(start)
+            with torch.cuda.stream(s):
+                self.extractor.forward_tokens(img[lo:hi], feat_bf16=fh[r0:r1, :c])
+                native.expand_head(fh[r0:r1], hw["w2a"], hw["b2a"], hw["w_cat"], hw["b_cat"], dim, out=code[r0:r1])
+                idx_i, _, loss_i = native.pq_assign(code[r0:r1], books, q0.normalize, False, zq_out=zq[r0:r1])
+                done = torch.cuda.Event()
+                done.record(s)
+            main.wait_event(done)
+            for t in (idx_i, loss_i):
+                t.record_stream(main)       # allocated on the side stream, consumed on the caller's
+            idx_parts.append(idx_i)
+            loss_parts.append(loss_i)
+        idx = torch.cat(idx_parts, dim=1)
+        per_pq = torch.stack(loss_parts).sum(0) / float(b * n * pqw.pq_dim)
+        outputs = {"vq-loss": ((q0.book + q0.beta) * per_pq).mean()}    # dino_pqgo.py:685-687 then :771-772
+        code_map, z_q = _nchw_of(code, b, gh, gw), _nchw_of(zq, b, gh, gw)
+        z_split = torch.chunk(code_map, chunks=pqw.num_pq, dim=1)
+        z_quantized = list(torch.chunk(z_q, chunks=pqw.num_pq, dim=1))
+        return code_map, z_q, (z_split, z_quantized, idx.reshape(pqw.num_pq, b, gh, gw)), outputs
+
     def forward(self, img: torch.Tensor, aug_img: torch.Tensor = None, img_pos: torch.Tensor = None,
                 it: int = 0, stage: int = 0):
         b, _, h, w = img.shape
         p = self.extractor.patch_size
         gh, gw = h // p, w // p
         if not self.training:
+            if self.eval_streams > 1 and img.is_cuda and b >= self.eval_streams:
+                return self._forward_eval_streams(img)
             code_rows, _ = self._code_rows(img)
             code = _nchw_of(code_rows, b, gh, gw)
             quantized, (z_split, z_quantized, z_index), outputs, _ = self.vq_blocks[0](

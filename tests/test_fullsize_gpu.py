@@ -65,3 +65,24 @@ def test_model_full_batch_equals_per_shard_results(pkg, dev):
             assert torch.equal(c2, code[s:s + 16]) and torch.equal(q2, quant[s:s + 16])
     assert index.shape == (8, 64, 40, 40)
     assert torch.isfinite(code).all()
+
+
+def test_streamed_eval_forward_equals_single_stream(pkg, dev):
+    """The eval forward spread over two or three HIP streams (image ranges of the batch) gives the
+    same code, quantised map and indices, bit for bit, as the single-stream forward."""
+    cfg = pkg.configs.S_CFG
+    m = pkg.build_model(cfg)
+    m.load_state_dict(pkg.synth.synth_pqgo_state(cfg, seed=1234), strict=True)
+    m = m.to(dev).eval()
+    img = pkg.synth.synth_images(7, 96, 64, seed=21).to(dev)
+    with torch.no_grad():
+        m.model.eval_streams = 1
+        ref = m.model(img=img)
+        for k in (2, 3):
+            m.model.eval_streams = k
+            for _ in range(2):   # second call: cached streams and workspaces
+                got = m.model(img=img)
+            torch.cuda.synchronize()
+            assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2][2], ref[2][2]), k
+            assert all(torch.equal(a, b) for a, b in zip(got[2][1], ref[2][1]))
+            assert abs(float(got[3]["vq-loss"]) - float(ref[3]["vq-loss"])) < 1e-6 * abs(float(ref[3]["vq-loss"])) + 1e-9
