@@ -24,17 +24,22 @@ def classify(name):
     return None
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
-rows = list(csv.DictReader(open(stats)))
-with open(os.path.join(out, f"{tag}_kernel_stats.csv"), "w") as f:
-    w = csv.writer(f)
-    w.writerow(["kernel", "class", "calls", "total_ms", "avg_us", "percent"])
-    for r in rows:
-        cls = classify(r["Name"])
-        if cls is None and float(r["Percentage"]) < 0.05:
-            continue
-        w.writerow([r["Name"][:110], cls or "torch/runtime", r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 3),
-                    round(float(r["AverageNs"]) / 1e3, 2), r["Percentage"]])
+# trace  = `bench.py --streams 1` (every kernel alone on the device: the durations the roofline figures use)
+# trace2 = the default command (batch spread over two streams: kernels of the two image ranges overlap)
+for sub, suffix in (("trace", ""), ("trace2", "_2streams")):
+    found = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
+    if not found:
+        continue
+    rows = list(csv.DictReader(open(found[0])))
+    with open(os.path.join(out, f"{tag}_kernel_stats{suffix}.csv"), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["kernel", "class", "calls", "total_ms", "avg_us", "percent"])
+        for r in rows:
+            cls = classify(r["Name"])
+            if cls is None and float(r["Percentage"]) < 0.05:
+                continue
+            w.writerow([r["Name"][:110], cls or "torch/runtime", r["Calls"], round(float(r["TotalDurationNs"]) / 1e6, 3),
+                        round(float(r["AverageNs"]) / 1e3, 2), r["Percentage"]])
 
 traffic = collections.defaultdict(lambda: {"fetch_raw_kb": 0.0, "write_raw_kb": 0.0, "launches_f": 0, "launches_w": 0})
 for counter, sub, fld, cnt in (("FETCH_SIZE", "fetch", "fetch_raw_kb", "launches_f"), ("WRITE_SIZE", "write", "write_raw_kb", "launches_w")):
