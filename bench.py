@@ -55,6 +55,7 @@ def algorithmic_work(cfg, batch, height, width):
         "gemm_proj": {"flops": 2.0 * rows * c * c},
         "gemm_fc1": {"flops": 2.0 * rows * c * 4 * c},
         "gemm_fc2": {"flops": 2.0 * rows * 4 * c * c},
+        "mlp_fused": {"flops": 4.0 * rows * 4 * c * c},     # fc1 + fc2 in one launch (ViT-S)
         "head_gemm1": {"flops": 2.0 * batch * n * c * c},
         "head_gemm2": {"flops": 2.0 * batch * n * 2 * c * d_out},
         "pq_prep": {"bytes": 2 * num_pq * k * (d_out // num_pq) * 4},
@@ -74,6 +75,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the batch's image ranges are spread over inside one step (1 = one stream)")
+    ap.add_argument("--dev", action="append", default=[], metavar="KNOB=INT",
+                    help="developer tuning knob of the library (equss_dev_KNOB), for experiments only")
     ap.add_argument("--cfg", choices=["s", "b"], default="s",
                     help="s = ViT-S/8, D=1024, 8x256 PQ (the headline workload); b = ViT-B/8, D=2048, 16x512 PQ "
                          "(use with --res 768 --batch 2..4)")
@@ -100,6 +103,9 @@ def main():
     model.load_state_dict(state, strict=True)
     model = model.to(dev).eval()
     model.model.eval_streams = max(1, args.streams)
+    for knob in args.dev:
+        name, value = knob.split("=")
+        getattr(pkg.native.load_library(), "equss_dev_" + name)(int(value))
     img = pkg.synth.synth_images(args.batch, args.res, args.res, seed=1 + rank).to(dev)
 
     def step():
@@ -157,7 +163,7 @@ def main():
     kernels = {}
     share = 1.0   # the profiled pass launches every kernel once over the whole batch
     for name, (ms, launches) in prof.items():
-        if launches == 0:
+        if launches == 0 or name not in work:
             continue
         avg_s = ms / launches / 1e3
         entry = {"ms_per_step": round(ms / args.steps, 4), "launches_per_step": launches / args.steps,

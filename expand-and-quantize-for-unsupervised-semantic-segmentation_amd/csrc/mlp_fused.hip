@@ -1,0 +1,367 @@
+// The whole MLP of a ViT-S block in one kernel (vision_transformer.py:58-64 inside :106-114):
+//     x += fc2(gelu(fc1(a))) ,   ln = LayerNorm(x)          a = LayerNorm2(x) in bf16, C = 384, hidden = 1536
+// without the (rows, 1536) hidden activation ever reaching HBM.  The two separate GEMMs write and
+// re-read 6 KB per token of hidden activation per block (630 MB per 64-image launch), and on this
+// part a GEMM's HBM time adds to its MFMA time instead of hiding behind it, so the round trip costs
+// its full bandwidth time.
+//
+// One persistent workgroup (8 waves, one per CU) owns a 128-row tile and walks the hidden dimension
+// in 12 chunks of 128:
+//     G1:  h = gelu(a[128 x 384] W1_c^T + b1_c)     6 K steps of 64; h (128 x 128 bf16) -> LDS
+//     G2:  acc2[128 x 384] += h W2[:, c]^T          2 K steps of 64, A operand straight from that LDS tile
+// acc2 starts from x + b2 and ends in the same residual + LayerNorm epilogue as the fc2 kernel it
+// replaces; the fp32 operation order per output element (k ascending, x-initialised accumulator) is
+// that kernel's too.  Operand slices arrive through a 2-slot LDS-DMA ring (global_load_lds_dwordx4, retired
+// with counted s_waitcnt vmcnt so that epilogue stores and residual loads may stay in flight);
+// fragment layout, chunk swizzle and the C^T trick are those of gemm8_bf16.hip.
+#include "equss_common.h"
+
+namespace {
+
+struct MlpArgs {
+    const u16* A; int64_t lda;        // LayerNorm2 output, (M, 384) bf16
+    const u16* W1; const float* b1;   // (1536, 384), (1536)
+    const u16* W2; const float* b2;   // (384, 1536), (384)
+    float* x; int64_t ldx;            // residual stream, updated in place
+    const float* gamma; const float* beta;
+    u16* ln; int64_t ld_ln;           // LayerNorm(x) for the next consumer (may be null)
+    float eps;
+    int M;
+};
+
+constexpr int C = 384, HID = 1536, BM = 128, HC = 128, BK = 64;
+constexpr int NW = 8, WN = 4;                    // waves as 2 (rows) x 4 (columns)
+constexpr int kThreads = NW * 64;
+constexpr int kStage = 384 * BK * 2;              // 48 KiB: the W2 slice of a G2 step; a G1 step (a slice + W1 slice) uses 32 KiB
+constexpr int S = 2;                              // ring slots: one stage in flight (three 32-KiB slots with 32-wide G2 steps measured 5 % slower)
+constexpr int kHc = BM * HC * 2;                  // 32 KiB
+constexpr int NCH = HID / HC;                     // 12 chunks
+constexpr int G1S = C / BK, G2S = HC / BK;        // 6 + 2 steps per chunk
+constexpr int G1L = 4, G2L = 6;                   // LDS-DMA loads per wave in a G1 / G2 stage
+constexpr int kLds = S * kStage + kHc + HID * 4 + 3 * C * 4 + BM * WN * 8;
+static_assert(kLds <= 163840, "LDS budget");
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const void __attribute__((address_space(1)))*)gsrc,
+        (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
+}
+
+template <int DIAG>
+__global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int fr = lane & 15, fq = lane >> 4;
+    char* hc = smem + S * kStage;
+    float* bias1_s = reinterpret_cast<float*>(hc + kHc);
+    float* bias2_s = bias1_s + HID;
+    float* gamma_s = bias2_s + C;
+    float* beta_s = gamma_s + C;
+    float2* red_s = reinterpret_cast<float2*>(beta_s + C);
+
+    // ---- tiles of this workgroup: XCD-contiguous order, as the GEMM kernels ---------------------
+    const int ntiles = (g.M + BM - 1) / BM;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int x_start = xcd * q8 + (xcd < r8 ? xcd : r8);
+    const int x_len = q8 + (xcd < r8 ? 1 : 0);
+    const int nslots = (gridDim.x + 7 - xcd) >> 3;
+    if (slot >= x_len) return;
+    const int my_tiles = (x_len - slot + nslots - 1) / nslots;
+    const int total = my_tiles * NCH * (G1S + G2S);
+
+    for (int i = tid; i < HID; i += kThreads) bias1_s[i] = g.b1[i];
+    for (int i = tid; i < C; i += kThreads) {
+        bias2_s[i] = g.b2[i];
+        gamma_s[i] = g.ln ? g.gamma[i] : 1.f;
+        beta_s[i] = g.ln ? g.beta[i] : 0.f;
+    }
+    __syncthreads();
+
+    // ---- LDS fragment offsets (rows of 128 B, 16-B chunks XOR-swizzled by (row >> 1) & 7) --------
+    int c_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) c_off[ks] = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
+    const int a_row = (wm * 64 + fr) * 128;        // + mt * 2048
+    const int w1_row = 16384 + (wn * 32 + fr) * 128;
+    const int w2_row = (wn * 96 + fr) * 128;
+
+    // ---- staging: 1-KiB pieces of 8 rows; piece p = wave + 8 i, so a wave's pieces share the swizzle --
+    const int st_row = lane >> 3;
+    const int st_chunk = ((lane & 7) ^ ((4 * (wave & 1) + (st_row >> 1)) & 7)) * 8;   // element offset in the row
+    const int w1_off = (wave * 8 + st_row) * C + st_chunk;          // + 64 * C for the second piece
+    const int w2_off = (wave * 8 + st_row) * HID + st_chunk;        // + 64 * HID per further piece
+    const u16* a_src[2];
+    int i_tile = slot, i_c = 0, i_j = 0, i_buf = 0, issued = 0;
+    auto set_a = [&](int logical) {
+        const int m0 = logical * BM;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int am = m0 + (wave + 8 * i) * 8 + st_row;
+            if (am > g.M - 1) am = g.M - 1;   // tail rows re-read the last row; outputs are masked
+            a_src[i] = g.A + (size_t)am * g.lda + st_chunk;
+        }
+    };
+    auto issue_one = [&]() {
+        if (issued >= total) return;
+        char* base = smem + i_buf * kStage;
+        if (DIAG == 1) {
+        } else if (i_j < G1S) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                glds16(a_src[i] + i_j * BK, base + (wave + 8 * i) * 1024);
+                glds16(g.W1 + (size_t)(i_c * HC + 64 * i) * C + w1_off + i_j * BK, base + 16384 + (wave + 8 * i) * 1024);
+            }
+        } else {
+            const u16* w2 = g.W2 + w2_off + i_c * HC + (i_j - G1S) * BK;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) glds16(w2 + (size_t)(64 * i) * HID, base + (wave + 8 * i) * 1024);
+        }
+        ++issued;
+        i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
+        if (++i_j == G1S + G2S) {
+            i_j = 0;
+            if (++i_c == NCH) {
+                i_c = 0;
+                i_tile += nslots;
+                if (issued < total) set_a(x_start + i_tile);
+            }
+        }
+    };
+    set_a(x_start + i_tile);
+#pragma unroll
+    for (int d = 0; d < S - 1; ++d) issue_one();
+
+    int c_buf = 0, step = 0;
+    // `extra`: vector-memory operations (epilogue stores, residual loads) this wave is known to have
+    // issued after the stage that was requested last; they may stay in flight across the next S - 1 waits.
+    int extra = 0, extra_age = 0;
+    // One ring step.  Operations retire in order, so "stage `step` has landed" is "at most what was issued
+    // after it is outstanding"; the barrier then covers the other waves' pieces and tells everyone that the
+    // slot consumed last step is free for the next stage.
+    auto sync_step = [&](bool next_is_g1) -> const char* {
+        const int younger = (S > 2 && step + 1 < total) ? (next_is_g1 ? G1L : G2L) : 0;
+        const int allow = younger + (step + 1 < total ? extra : 0);
+#define EQUSS_W(n) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(n) : "memory")
+        if (allow >= 60) EQUSS_W(60);
+        else if (allow >= 24) EQUSS_W(24);
+        else EQUSS_W(0);
+#undef EQUSS_W
+        if (extra_age > 0 && --extra_age == 0) extra = 0;
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue_one();
+        const char* base = smem + c_buf * kStage;
+        c_buf = c_buf + 1 == S ? 0 : c_buf + 1;
+        ++step;
+        return base;
+    };
+
+    int c_tile = slot;
+    for (int t = 0; t < my_tiles; ++t, c_tile += nslots) {
+        const int m0 = (x_start + c_tile) * BM;
+        f32x4 acc2[6][4];   // [nt][mt]: rows wm*64 + mt*16 + fr, columns wn*96 + nt*16 + fq*4 + 0..3
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const int n = wn * 96 + nt * 16 + fq * 4;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + wm * 64 + mt * 16 + fr;
+                f32x4 o = {0.f, 0.f, 0.f, 0.f};
+                if (m < g.M) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
+                acc2[nt][mt] = o;   // (+ bias before the first use below: the loads get the six G1 steps to arrive)
+            }
+        }
+        // residual loads (and, after the first tile, the previous epilogue's stores) of a full tile are a
+        // known number of operations younger than the stage in flight
+        const bool full = m0 + BM <= g.M;
+        extra = full ? 24 + (t > 0 ? 24 + (g.ln ? 12 : 0) : 0) : 0;
+        extra_age = S - 1;
+        for (int c = 0; c < NCH; ++c) {
+            // ---- G1: h = a W1_c^T -------------------------------------------------------------------
+            f32x4 acc1[2][4];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < G1S; ++kt) {
+                const char* base = sync_step(kt + 1 < G1S);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 af[4], wf[2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 2048 + c_off[ks]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w1_row + i * 2048 + c_off[ks]);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            if (DIAG != 2) acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc1[nt][mt], 0, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+            }
+            // ---- gelu(h + b1) -> LDS as two 64-wide K stages in the ring's row format -----------------
+            // (every wave passed a barrier after its last read of the previous chunk's h)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                const int nloc = wn * 32 + nt * 16 + fq * 4;          // column within the chunk
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias1_s + c * HC + nloc);
+                const int half = nloc >> 6, n6 = nloc & 63;
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = wm * 64 + mt * 16 + fr;
+                    f32x4 v = acc1[nt][mt];
+                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
+                    const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
+                    uint2 pk;
+                    pk.x = equss::pack_bf16(g0.x, g0.y);
+                    pk.y = equss::pack_bf16(g1.x, g1.y);
+                    *reinterpret_cast<uint2*>(hc + half * 16384 + row * 128 + (((n6 >> 3) ^ ((row >> 1) & 7)) * 16) +
+                                              ((n6 >> 2) & 1) * 8) = pk;
+                }
+            }
+            if (c == 0) {
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias2_s + wn * 96 + nt * 16 + fq * 4);
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        acc2[nt][mt].x += b4.x; acc2[nt][mt].y += b4.y; acc2[nt][mt].z += b4.z; acc2[nt][mt].w += b4.w;
+                    }
+                }
+            }
+            // ---- G2: acc2 += h W2[:, c]^T  (the step's wait + barrier publishes h) ---------------------
+            for (int kt = 0; kt < G2S; ++kt) {
+                const char* base = sync_step(kt + 1 == G2S);
+                const char* hb = hc + kt * 16384;
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8 hf[4], wf[6];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) hf[i] = *reinterpret_cast<const bf16x8*>(hb + a_row + i * 2048 + c_off[ks]);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w2_row + i * 2048 + c_off[ks]);
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            if (DIAG != 2) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], hf[mt], acc2[nt][mt], 0, 0, 0);
+                }
+                asm volatile("" ::: "memory");
+            }
+        }
+        // ---- epilogue: x back, LayerNorm statistics, normalised rows as bf16 (as gemm8's residual epilogue) --
+        float s1[4], s2[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m0 + wm * 64 + mt * 16 + fr;
+            s1[mt] = 0.f; s2[mt] = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt) {
+                const int n = wn * 96 + nt * 16 + fq * 4;
+                const f32x4 v = acc2[nt][mt];
+                if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+                s1[mt] += (v.x + v.y) + (v.z + v.w);
+                s2[mt] += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+            }
+            s1[mt] += __shfl_xor(s1[mt], 16, 64); s2[mt] += __shfl_xor(s2[mt], 16, 64);
+            s1[mt] += __shfl_xor(s1[mt], 32, 64); s2[mt] += __shfl_xor(s2[mt], 32, 64);
+            if (fq == 0) red_s[(wm * 64 + mt * 16 + fr) * WN + wn] = make_float2(s1[mt], s2[mt]);
+        }
+        if (g.ln) {
+            constexpr int ROWSTRIDE = 96 * 2 + 16, OCH = 12, PER_LANE = 16 * OCH / 64;
+            // the slot consumed by the last step is free (the other one is receiving the next tile's first stage)
+            char* stg = smem + (c_buf == 0 ? S - 1 : c_buf - 1) * kStage + wave * (kStage / NW);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // partial sums visible; that slot no longer read
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float2* pr = red_s + (wm * 64 + mt * 16 + fr) * WN;
+                const float2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+                const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / C);
+                const float ex2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / C);
+                const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt) {
+                    const int n = wn * 96 + nt * 16 + fq * 4;
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma_s + n);
+                    const f32x4 be = *reinterpret_cast<const f32x4*>(beta_s + n);
+                    const f32x4 v = acc2[nt][mt];
+                    uint2 pk;
+                    pk.x = equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y));
+                    pk.y = equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w));
+                    *reinterpret_cast<uint2*>(stg + fr * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
+                }
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) {
+                    const int idx = j * 64 + lane;
+                    const int row = idx / OCH, ch = idx % OCH;
+                    const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
+                    const int m = m0 + wm * 64 + mt * 16 + row;
+                    if (m < g.M) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * 96 + ch * 8) = d;
+                }
+                asm volatile("" ::: "memory");
+            }
+        } else {
+            // red_s is rewritten by the next tile's epilogue only after ~100 barriers: nothing to wait for
+        }
+    }
+}
+
+}  // namespace
+
+int g_diag = 0;
+extern "C" void equss_dev_mlp_diag(int d) { g_diag = d; }
+
+namespace equss {
+
+bool mlp_fused_supports(int C_, int hidden) { return C_ == C && hidden == HID; }
+
+int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+              int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s) {
+    MlpArgs g;
+    g.A = reinterpret_cast<const u16*>(a); g.lda = lda;
+    g.W1 = reinterpret_cast<const u16*>(w1); g.b1 = b1;
+    g.W2 = reinterpret_cast<const u16*>(w2); g.b2 = b2;
+    g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta;
+    g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps; g.M = M;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+            return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
+        attr_done = true;
+    }
+    const int ntiles = (M + BM - 1) / BM;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    if (g_diag == 1) hipLaunchKernelGGL(mlp_kernel<1>, dim3(grid), dim3(kThreads), kLds, s, g);
+    else if (g_diag == 2) hipLaunchKernelGGL(mlp_kernel<2>, dim3(grid), dim3(kThreads), kLds, s, g);
+    else hipLaunchKernelGGL(mlp_kernel<0>, dim3(grid), dim3(kThreads), kLds, s, g);
+    return check_launch("mlp_kernel");
+}
+
+}  // namespace equss
+
+// x += fc2(gelu(fc1(a))), ln_out = LayerNorm(x) (ln_out may be null).  C = 384, hidden = 1536 only.
+extern "C" int equss_mlp_resid_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2,
+                                       const float* b2, float* x, int64_t ldx, const float* gamma, const float* beta,
+                                       void* ln_out, int64_t ld_ln, int M, int C_, int hidden, float eps, void* stream) {
+    if (!a || !w1 || !b1 || !w2 || !b2 || !x || (ln_out && (!gamma || !beta)))
+        return equss::fail(EQUSS_E_NULL, "mlp_resid_ln: null pointer argument");
+    if (M <= 0) return equss::fail(EQUSS_E_SHAPE, "mlp_resid_ln: M=%d must be positive", M);
+    if (!equss::mlp_fused_supports(C_, hidden))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "mlp_resid_ln: C=%d hidden=%d (384 and 1536 only)", C_, hidden);
+    if (lda < C_ || ldx < C_ || (ln_out && ld_ln < C_) || (lda % 8) || (ldx % 4) || (ld_ln % 8) || ((uintptr_t)a % 16) ||
+        ((uintptr_t)w1 % 16) || ((uintptr_t)w2 % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
+        return equss::fail(EQUSS_E_ALIGN, "mlp_resid_ln: operands must be 16-byte aligned with padded leading dimensions");
+    return equss::mlp_fused(a, lda, w1, b1, w2, b2, x, ldx, gamma, beta, ln_out, ld_ln, M, eps,
+                            reinterpret_cast<hipStream_t>(stream));
+}

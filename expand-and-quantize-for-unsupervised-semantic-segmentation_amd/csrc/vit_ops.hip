@@ -7,6 +7,9 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
               int M, int N, int K, int epilogue, hipStream_t s);
 int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s);
 bool gemm8_resid_ln_supports(int N, int K);
+bool mlp_fused_supports(int C, int hidden);
+int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+              int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
 int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
                    const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, int N, int K, float eps,
                    hipStream_t s);
@@ -242,6 +245,32 @@ int resid_ln_balanced(const void* A, int64_t lda, const void* W, int64_t ldw, co
     return equss::check_launch("layernorm_rowtile_kernel");
 }
 
+// x += fc2(gelu(fc1(a))), ln = LayerNorm(x) for C = 384: the fused MLP kernel on as many whole rounds of
+// 128-row tiles as the chip's 256 CUs take, and the trailing rows (a partly filled extra round would
+// cost a full tile time, ~100 us) through the two-GEMM route with small tiles.  Both routes give a row
+// the same bits.  `hid` is scratch for the trailing rows' hidden activation (m_tail x 1536 bf16).
+int g_mlp_tail_max = 128;   // trailing tiles (of 256) up to which the split pays
+int mlp_balanced(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+                 int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, void* hid, int M, float eps,
+                 hipStream_t s) {
+    const int C = 384, H = 1536;
+    const int tiles = (M + 127) / 128, rounds = tiles / 256, rem = tiles % 256;
+    if (rounds < 1 || rem == 0 || rem > g_mlp_tail_max || !hid)
+        return equss::mlp_fused(a, lda, w1, b1, w2, b2, x, ldx, gamma, beta, ln, ld_ln, M, eps, s);
+    const int m_main = rounds * 256 * 128, m_tail = M - m_main;
+    int rc = equss::mlp_fused(a, lda, w1, b1, w2, b2, x, ldx, gamma, beta, ln, ld_ln, m_main, eps, s);
+    if (rc) return rc;
+    const u16* a_tail = reinterpret_cast<const u16*>(a) + (size_t)m_main * lda;
+    float* x_tail = x + (size_t)m_main * ldx;
+    rc = equss::gemm_bf16(a_tail, lda, w1, C, b1, hid, H, m_tail, H, C, EQUSS_EPI_GELU_BF16, s);
+    if (rc) return rc;
+    rc = equss::gemm_bf16(hid, H, w2, H, b2, x_tail, ldx, m_tail, C, H, EQUSS_EPI_RESID_F32, s);
+    if (rc || !ln) return rc;
+    hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, ldx, gamma, beta,
+                       reinterpret_cast<u16*>(ln) + (size_t)m_main * ld_ln, ld_ln, m_tail, eps);
+    return equss::check_launch("layernorm_rowtile_kernel");
+}
+
 int patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls, const float* pos,
                  float* x, void* ws, int B, int H, int W, int P, int C, hipStream_t s) {
     PatchWs w = carve_patch(ws, B, H, W, P, C);
@@ -295,6 +324,10 @@ extern "C" int equss_patch_tokens(const float* img, const void* w_patch, const f
         return equss::fail(EQUSS_E_WORKSPACE, "patch_tokens: workspace too small");
     return patch_tokens(img, w_patch, b_patch, cls, pos, x, workspace, B, H, W, P, C, reinterpret_cast<hipStream_t>(stream));
 }
+
+int g_mlp_fused = 1;   // developer switch: 0 = fc1 and fc2 as two GEMM launches
+extern "C" void equss_dev_mlp_fused(int on) { g_mlp_fused = on; }
+extern "C" void equss_dev_mlp_tail_max(int n) { g_mlp_tail_max = n; }
 
 extern "C" size_t equss_vit_workspace_bytes(const EqussVit* vit, int B, int H, int W) {
     if (!vit || B <= 0 || H <= 0 || W <= 0 || vit->patch <= 0) return 0;
@@ -350,6 +383,11 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         } else {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))
             EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
+        }
+        if (fuse && g_mlp_fused && equss::mlp_fused_supports(C, 4 * C)) {
+            const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
+            EQUSS_STEP(EQUSS_K_MLP_FUSED, mlp_balanced(w.ln, C, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, C, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, C, w.hid, rows, 1e-6f, s))
+            continue;
         }
         EQUSS_STEP(EQUSS_K_GEMM_FC1, equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))
         if (fuse) {

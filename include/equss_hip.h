@@ -80,7 +80,8 @@ enum {
     EQUSS_K_PQ_ASSIGN = 10,
     EQUSS_K_PROBE_TABLE = 11,  /* low-resolution probe products + neighbour Gram entries */
     EQUSS_K_PROBE_PIXELS = 12, /* per-pixel interpolation, arg-max, losses */
-    EQUSS_K_COUNT = 13
+    EQUSS_K_MLP_FUSED = 13,    /* fc1 + GELU + fc2 + residual + LayerNorm in one kernel */
+    EQUSS_K_COUNT = 14
 };
 int equss_profile_enable(int max_pairs);
 int equss_profile_read(double* ms, int64_t* launches, int reset);
@@ -149,6 +150,16 @@ int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, cons
 int equss_gemm_resid_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                              float* x, int64_t ldx, const float* gamma, const float* beta, void* ln_out,
                              int64_t ld_ln, int M, int N, int K, float eps, void* stream);
+
+/* The whole MLP of a transformer block fused with the residual update and the LayerNorm that follows
+ * (vision_transformer.py:58-64 inside :106-114):
+ *   x += gelu(a * W1^T + b1) * W2^T + b2 ;  ln_out = LayerNorm(x) * gamma + beta in bf16 (or NULL).
+ *   a (M, C) bf16 = LayerNorm2 output; W1 (hidden, C) bf16; W2 (C, hidden) bf16; x (M, C) fp32 in place.
+ * The (M, hidden) activation never reaches HBM.  C = 384 with hidden = 1536 only (ViT-S); other
+ * widths use equss_gemm_bf16 (EQUSS_EPI_GELU_BF16) followed by equss_gemm_resid_ln_bf16. */
+int equss_mlp_resid_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2,
+                            const float* b2, float* x, int64_t ldx, const float* gamma, const float* beta,
+                            void* ln_out, int64_t ld_ln, int M, int C, int hidden, float eps, void* stream);
 
 /* Multi-head self-attention softmax(q k^T * scale) v without materialising the (N x N) matrix
  * (vision_transformer.py:81-88; the attention matrix it returns is discarded by

@@ -227,3 +227,37 @@ def test_gemm_residual_layernorm_fused(m, k, native, dev):
     assert torch.equal(x2, x)
     with pytest.raises(ValueError):
         native.gemm_resid_ln_bf16(a.to(dev), _bf(torch.zeros(256, k)).to(dev), None, torch.zeros(m, 256, device=dev), want_ln=False)
+
+
+@pytest.mark.parametrize("m", [1, 130, 128 * 5 + 77, 128 * 300 + 5])
+def test_mlp_fused_equals_the_two_gemm_route(m, native, dev):
+    """fc1 + GELU + fc2 + residual + LayerNorm in one kernel against the two-launch route
+    (equss_gemm_bf16 with the GELU epilogue, then equss_gemm_resid_ln_bf16): same operand rounding and
+    the same fp32 operation order per element, so the results are compared bit for bit; plus an fp64
+    reference of the whole expression."""
+    g = _rng(m)
+    c, hid = 384, 1536
+    a = _bf(torch.from_numpy(g.standard_normal((m, c)).astype(np.float32)))
+    w1 = _bf(torch.from_numpy((g.standard_normal((hid, c)) / math.sqrt(c)).astype(np.float32)))
+    b1 = torch.from_numpy((0.3 * g.standard_normal(hid)).astype(np.float32))
+    w2 = _bf(torch.from_numpy((g.standard_normal((c, hid)) / math.sqrt(hid)).astype(np.float32)))
+    b2 = torch.from_numpy((0.3 * g.standard_normal(c)).astype(np.float32))
+    x0 = torch.from_numpy(g.standard_normal((m, c)).astype(np.float32))
+    gamma = torch.from_numpy((1 + 0.1 * g.standard_normal(c)).astype(np.float32))
+    beta = torch.from_numpy((0.1 * g.standard_normal(c)).astype(np.float32))
+    d = lambda t: t.to(dev)   # noqa: E731
+    x_f = d(x0.clone())
+    ln_f = native.mlp_resid_ln_bf16(d(a), d(w1), d(b1), d(w2), d(b2), x_f, d(gamma), d(beta), 1e-6)
+    x_u = d(x0.clone())
+    hidden = native.gemm_bf16(d(a), d(w1), d(b1), 1)
+    ln_u = native.gemm_resid_ln_bf16(hidden, d(w2), d(b2), x_u, d(gamma), d(beta), 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(x_f, x_u)
+    assert torch.equal(ln_f, ln_u)
+    h64 = F.gelu(a.double() @ w1.double().t() + b1.double())
+    ref = x0.double() + _bf(h64.float()).double() @ w2.double().t() + b2.double()
+    assert float((x_f.cpu().double() - ref).abs().max()) < 2e-2     # (bf16 rounding of the hidden activation flips at ties)
+    assert float((x_f.cpu().double() - ref).abs().mean()) < 2e-4
+    x_n = d(x0.clone())
+    assert native.mlp_resid_ln_bf16(d(a), d(w1), d(b1), d(w2), d(b2), x_n, want_ln=False) is None
+    assert torch.equal(x_n, x_f)
