@@ -47,7 +47,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
         (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
-template <int DIAG>
 __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -108,8 +107,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     auto issue_one = [&]() {
         if (issued >= total) return;
         char* base = smem + i_buf * kStage;
-        if (DIAG == 1) {
-        } else if (i_j < G1S) {
+        if (i_j < G1S) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 glds16(a_src[i] + i_j * BK, base + (wave + 8 * i) * 1024);
@@ -200,7 +198,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            if (DIAG != 2) acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc1[nt][mt], 0, 0, 0);
+                            acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc1[nt][mt], 0, 0, 0);
                 }
                 asm volatile("" ::: "memory");
             }
@@ -250,7 +248,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                     for (int nt = 0; nt < 6; ++nt)
 #pragma unroll
                         for (int mt = 0; mt < 4; ++mt)
-                            if (DIAG != 2) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], hf[mt], acc2[nt][mt], 0, 0, 0);
+                            acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], hf[mt], acc2[nt][mt], 0, 0, 0);
                 }
                 asm volatile("" ::: "memory");
             }
@@ -317,9 +315,6 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
 
 }  // namespace
 
-int g_diag = 0;
-extern "C" void equss_dev_mlp_diag(int d) { g_diag = d; }
-
 namespace equss {
 
 bool mlp_fused_supports(int C_, int hidden) { return C_ == C && hidden == HID; }
@@ -334,17 +329,14 @@ int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const
     g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps; g.M = M;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) !=
+            hipSuccess)
             return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
         attr_done = true;
     }
     const int ntiles = (M + BM - 1) / BM;
     const int grid = ntiles < 256 ? ntiles : 256;
-    if (g_diag == 1) hipLaunchKernelGGL(mlp_kernel<1>, dim3(grid), dim3(kThreads), kLds, s, g);
-    else if (g_diag == 2) hipLaunchKernelGGL(mlp_kernel<2>, dim3(grid), dim3(kThreads), kLds, s, g);
-    else hipLaunchKernelGGL(mlp_kernel<0>, dim3(grid), dim3(kThreads), kLds, s, g);
+    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(kThreads), kLds, s, g);
     return check_launch("mlp_kernel");
 }
 

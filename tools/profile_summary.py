@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-CLASS = [("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
+CLASS = [("mlp_kernel", "mlp_fused"), ("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
          ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"),
          ("layernorm_rowtile_kernel", "layernorm_tail(proj,fc2)"), ("layernorm_kernel", "layernorm"),
          ("gemm8_kernel<1,", "gemm_fc1"), ("gemm8_kernel<0,", "gemm_bf16out"), ("gemm8_kernel<2,", "head_gemm1"),
@@ -69,6 +69,7 @@ with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as f:
 flat = {"attention": summary.get("attention", {}).get("hbm_bytes_per_launch"),
         "pq_assign": summary.get("pq_assign", {}).get("hbm_bytes_per_launch"),
         "gemm_fc1": summary.get("gemm_fc1", {}).get("hbm_bytes_per_launch"),
+        "mlp_fused": summary.get("mlp_fused", {}).get("hbm_bytes_per_launch"),
         "gemm_qkv": summary.get("gemm_bf16out", {}).get("hbm_bytes_per_launch")}
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(flat, f, indent=1, sort_keys=True)
