@@ -21,7 +21,8 @@ from .evaluator import UnSegEvaluator, ClusterLookup  # noqa: F401
 from .metric import UnSegMetrics  # noqa: F401
 from .wrapper import PQGOWrapper, build_model  # noqa: F401
 from . import quantizer  # noqa: F401
+from .index_dump import CodeIndexDump  # noqa: F401
 
-__all__ = ["configs", "synth", "native", "dist_utils", "quantizer", "DinoFeaturizer", "VisionTransformer",
+__all__ = ["CodeIndexDump", "configs", "synth", "native", "dist_utils", "quantizer", "DinoFeaturizer", "VisionTransformer",
            "DIONPQGO", "Codebook", "ProductQuantizerWrapper", "STEGOLoss", "UnSegEvaluator", "ClusterLookup",
            "UnSegMetrics", "PQGOWrapper", "build_model"]

@@ -156,3 +156,30 @@ def test_point_sampling_matches_grid_sample(pkg):
     (g_got,) = torch.autograd.grad((got * wgt).sum(), t)
     (g_ref,) = torch.autograd.grad((ref0 * wgt[0]).sum() + (ref1 * wgt[1]).sum(), t)
     torch.testing.assert_close(g_got, g_ref, rtol=1e-5, atol=1e-6)
+
+
+def test_code_index_dump_round_trip(pkg, tmp_path):
+    """The index dump (train.py:283-329 sketch): nearest-upsampled indices next to labels, appended
+    batch by batch, readable with numpy.load; against F.interpolate(mode="nearest")."""
+    import torch.nn.functional as F
+    torch.manual_seed(0)
+    num_pq, h, w, hh, ww = 3, 5, 4, 40, 32
+    prefix = str(tmp_path / "dump" / "val")
+    want_idx, want_lab = [], []
+    with pkg.CodeIndexDump(prefix, num_pq) as dump:
+        for b in (2, 1):
+            z = torch.randint(0, 512, (num_pq, b, h, w))
+            lab = torch.randint(-1, 27, (b, hh, ww))
+            dump.append(z, lab)
+            up = F.interpolate(z.permute(1, 0, 2, 3).float(), size=(hh, ww), mode="nearest")     # (b, num_pq, H, W)
+            want_idx.append(up.reshape(b, num_pq, -1).permute(0, 2, 1).reshape(-1, num_pq).numpy())
+            want_lab.append(lab.reshape(-1).numpy())
+    idx = np.load(prefix + "_index.npy", mmap_mode="r")
+    lab = np.load(prefix + "_label.npy")
+    assert idx.dtype == np.int16 and idx.shape == (3 * hh * ww, num_pq) and lab.shape == (3 * hh * ww,)
+    assert np.array_equal(idx, np.concatenate(want_idx).astype(np.int16))
+    assert np.array_equal(lab, np.concatenate(want_lab).astype(np.int16))
+    with pkg.CodeIndexDump(prefix + "_low", num_pq, upsample=False) as dump:
+        z = torch.randint(0, 512, (num_pq, 2, h, w))
+        dump.append(z, torch.zeros(2, hh, ww, dtype=torch.long))
+    assert np.load(prefix + "_low_index.npy").shape == (2 * h * w, num_pq)
