@@ -56,6 +56,7 @@ def algorithmic_work(cfg, batch, height, width):
         "gemm_fc1": {"flops": 2.0 * rows * c * 4 * c},
         "gemm_fc2": {"flops": 2.0 * rows * 4 * c * c},
         "mlp_fused": {"flops": 4.0 * rows * 4 * c * c},     # fc1 + fc2 in one launch (ViT-S)
+        "block_tail": {"flops": 2.0 * rows * c * c + 4.0 * rows * 4 * c * c},   # proj + fc1 + fc2 in one launch (ViT-S)
         "head_gemm1": {"flops": 2.0 * batch * n * c * c},
         "head_gemm2": {"flops": 2.0 * batch * n * 2 * c * d_out},
         "pq_prep": {"bytes": 2 * num_pq * k * (d_out // num_pq) * 4},

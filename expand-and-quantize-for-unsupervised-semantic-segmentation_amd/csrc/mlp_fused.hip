@@ -19,6 +19,11 @@
 namespace {
 
 struct MlpArgs {
+    // PROJ variant only: attention output (M, 384) bf16, projection weights (384, 384) / bias, LayerNorm2
+    // parameters; A is then an output too (LayerNorm2(x) is written there before the MLP reads it back)
+    const u16* A0; int64_t lda0;
+    const u16* Wp; const float* bp;
+    const float* gamma2; const float* beta2;
     const u16* A; int64_t lda;        // LayerNorm2 output, (M, 384) bf16
     const u16* W1; const float* b1;   // (1536, 384), (1536)
     const u16* W2; const float* b2;   // (384, 1536), (384)
@@ -38,7 +43,8 @@ constexpr int kHc = BM * HC * 2;                  // 32 KiB
 constexpr int NCH = HID / HC;                     // 12 chunks
 constexpr int G1S = C / BK, G2S = HC / BK;        // 6 + 2 steps per chunk
 constexpr int G1L = 4, G2L = 6;                   // LDS-DMA loads per wave in a G1 / G2 stage
-constexpr int kLds = S * kStage + kHc + HID * 4 + 3 * C * 4 + BM * WN * 8;
+constexpr int G0S = C / 32;                       // PROJ variant: 12 steps of 32 (attention slice 8 KiB + Wp slice 24 KiB)
+constexpr int kLds = S * kStage + kHc + HID * 4 + 6 * C * 4 + BM * WN * 8;
 static_assert(kLds <= 163840, "LDS budget");
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -47,6 +53,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
         (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+template <bool PROJ>
 __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -59,7 +66,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     float* bias2_s = bias1_s + HID;
     float* gamma_s = bias2_s + C;
     float* beta_s = gamma_s + C;
-    float2* red_s = reinterpret_cast<float2*>(beta_s + C);
+    float* biasp_s = beta_s + C;
+    float* gamma2_s = biasp_s + C;
+    float* beta2_s = gamma2_s + C;
+    float2* red_s = reinterpret_cast<float2*>(beta2_s + C);
 
     // ---- tiles of this workgroup: XCD-contiguous order, as the GEMM kernels ---------------------
     const int ntiles = (g.M + BM - 1) / BM;
@@ -70,13 +80,18 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     const int nslots = (gridDim.x + 7 - xcd) >> 3;
     if (slot >= x_len) return;
     const int my_tiles = (x_len - slot + nslots - 1) / nslots;
-    const int total = my_tiles * NCH * (G1S + G2S);
+    const int total = my_tiles * ((PROJ ? G0S : 0) + NCH * (G1S + G2S));
 
     for (int i = tid; i < HID; i += kThreads) bias1_s[i] = g.b1[i];
     for (int i = tid; i < C; i += kThreads) {
         bias2_s[i] = g.b2[i];
         gamma_s[i] = g.ln ? g.gamma[i] : 1.f;
         beta_s[i] = g.ln ? g.beta[i] : 0.f;
+        if (PROJ) {
+            biasp_s[i] = g.bp[i];
+            gamma2_s[i] = g.gamma2[i];
+            beta2_s[i] = g.beta2[i];
+        }
     }
     __syncthreads();
 
@@ -93,8 +108,14 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     const int st_chunk = ((lane & 7) ^ ((4 * (wave & 1) + (st_row >> 1)) & 7)) * 8;   // element offset in the row
     const int w1_off = (wave * 8 + st_row) * C + st_chunk;          // + 64 * C for the second piece
     const int w2_off = (wave * 8 + st_row) * HID + st_chunk;        // + 64 * HID per further piece
+    // G0 slices are 32 wide: rows of 64 B, 16-B chunks swizzled by (row >> 2) & 3, pieces of 16 rows
+    const int g0_chunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
+    const int g0_row = wave * 16 + (lane >> 2);                     // + 128 per further piece
+    const int g0_off = (fq ^ ((fr >> 2) & 3)) * 16;                 // fragment read: chunk fq of row fr
     const u16* a_src[2];
-    int i_tile = slot, i_c = 0, i_j = 0, i_buf = 0, issued = 0;
+    const u16* a0_src = nullptr;
+    int i_tile = slot, i_p = 0, i_c = 0, i_j = 0, i_buf = 0, issued = 0;
+    bool hold_ok = false;   // PROJ: the tile's LayerNorm2 rows are in memory, the first G1 stage may be requested
     auto set_a = [&](int logical) {
         const int m0 = logical * BM;
 #pragma unroll
@@ -103,10 +124,29 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             if (am > g.M - 1) am = g.M - 1;   // tail rows re-read the last row; outputs are masked
             a_src[i] = g.A + (size_t)am * g.lda + st_chunk;
         }
+        if (PROJ) {
+            int am = m0 + g0_row;
+            if (am > g.M - 1) am = g.M - 1;
+            a0_src = g.A0 + (size_t)am * g.lda0 + g0_chunk;
+        }
     };
     auto issue_one = [&]() {
         if (issued >= total) return;
         char* base = smem + i_buf * kStage;
+        if (PROJ && i_p < G0S) {
+            glds16(a0_src + i_p * 32, base + wave * 1024);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                glds16(g.Wp + (size_t)(g0_row + 128 * i) * C + g0_chunk + i_p * 32, base + 8192 + (wave + 8 * i) * 1024);
+            ++i_p;
+            ++issued;
+            i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
+            return;
+        }
+        if (PROJ && i_c == 0 && i_j == 0) {
+            if (!hold_ok) return;   // asked for again once the tile's LayerNorm2 rows have been written
+            hold_ok = false;
+        }
         if (i_j < G1S) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -124,6 +164,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             i_j = 0;
             if (++i_c == NCH) {
                 i_c = 0;
+                i_p = 0;
                 i_tile += nslots;
                 if (issued < total) set_a(x_start + i_tile);
             }
@@ -178,6 +219,92 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
         const bool full = m0 + BM <= g.M;
         extra = full ? 24 + (t > 0 ? 24 + (g.ln ? 12 : 0) : 0) : 0;
         extra_age = S - 1;
+        if (PROJ) {
+            // ---- G0: acc2 = x + bp + att Wp^T  (the projection with its residual, vision_transformer.py:110)
+            for (int kt = 0; kt < G0S; ++kt) {
+                const char* base = sync_step(false);
+                if (kt == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt) {
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(biasp_s + wn * 96 + nt * 16 + fq * 4);
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt) {
+                            acc2[nt][mt].x += b4.x; acc2[nt][mt].y += b4.y; acc2[nt][mt].z += b4.z; acc2[nt][mt].w += b4.w;
+                        }
+                    }
+                }
+                bf16x8 af[4], wf[6];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + (wm * 64 + i * 16 + fr) * 64 + g0_off);
+#pragma unroll
+                for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + 8192 + (wn * 96 + i * 16 + fr) * 64 + g0_off);
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt)
+                        acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc2[nt][mt], 0, 0, 0);
+                asm volatile("" ::: "memory");
+            }
+            // ---- LayerNorm2 of the updated rows -> memory (g.A), from where the G1 steps stage it ------------
+            {
+                float s1[4], s2[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    s1[mt] = 0.f; s2[mt] = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt) {
+                        const f32x4 v = acc2[nt][mt];
+                        s1[mt] += (v.x + v.y) + (v.z + v.w);
+                        s2[mt] += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+                    }
+                    s1[mt] += __shfl_xor(s1[mt], 16, 64); s2[mt] += __shfl_xor(s2[mt], 16, 64);
+                    s1[mt] += __shfl_xor(s1[mt], 32, 64); s2[mt] += __shfl_xor(s2[mt], 32, 64);
+                    if (fq == 0) red_s[(wm * 64 + mt * 16 + fr) * WN + wn] = make_float2(s1[mt], s2[mt]);
+                }
+                constexpr int ROWSTRIDE = 96 * 2 + 16, OCH = 12, PER_LANE = 16 * OCH / 64;
+                char* stg = smem + (c_buf == 0 ? S - 1 : c_buf - 1) * kStage + wave * (kStage / NW);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();  // partial sums visible; the slot of the last G0 step no longer read
+                asm volatile("" ::: "memory");
+                u16* ln2 = const_cast<u16*>(g.A);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const float2* pr = red_s + (wm * 64 + mt * 16 + fr) * WN;
+                    const float2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
+                    const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / C);
+                    const float ex2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / C);
+                    const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt) {
+                        const int n = wn * 96 + nt * 16 + fq * 4;
+                        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma2_s + n);
+                        const f32x4 be = *reinterpret_cast<const f32x4*>(beta2_s + n);
+                        const f32x4 v = acc2[nt][mt];
+                        uint2 pk;
+                        pk.x = equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y));
+                        pk.y = equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w));
+                        *reinterpret_cast<uint2*>(stg + fr * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
+                    }
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int j = 0; j < PER_LANE; ++j) {
+                        const int idx = j * 64 + lane;
+                        const int row = idx / OCH, ch = idx % OCH;
+                        const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
+                        const int m = m0 + wm * 64 + mt * 16 + row;
+                        if (m < g.M) *reinterpret_cast<uint4*>(ln2 + (size_t)m * g.lda + wn * 96 + ch * 8) = d;
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                // Workgroup-scope release / acquire: the stores have completed, every wave of the workgroup
+                // (one CU, one vector L1) is past the barrier, then the rows are read back by LDS-DMA.
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                hold_ok = true;
+                issue_one();
+            }
+        }
         for (int c = 0; c < NCH; ++c) {
             // ---- G1: h = a W1_c^T -------------------------------------------------------------------
             f32x4 acc1[2][4];
@@ -237,13 +364,13 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             for (int kt = 0; kt < G2S; ++kt) {
                 const char* base = sync_step(kt + 1 == G2S);
                 const char* hb = hc + kt * 16384;
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll 1
+                for (int ks = 0; ks < 2; ++ks) {   // (not unrolled: both sub-steps' fragments in flight would spill)
                     bf16x8 hf[4], wf[6];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) hf[i] = *reinterpret_cast<const bf16x8*>(hb + a_row + i * 2048 + c_off[ks]);
+                    for (int i = 0; i < 4; ++i) hf[i] = *reinterpret_cast<const bf16x8*>(hb + a_row + i * 2048 + (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16));
 #pragma unroll
-                    for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w2_row + i * 2048 + c_off[ks]);
+                    for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w2_row + i * 2048 + (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16));
 #pragma unroll
                     for (int nt = 0; nt < 6; ++nt)
 #pragma unroll
@@ -319,25 +446,51 @@ namespace equss {
 
 bool mlp_fused_supports(int C_, int hidden) { return C_ == C && hidden == HID; }
 
+namespace {
+template <bool PROJ>
+int launch_mlp(const MlpArgs& g, hipStream_t s) {
+    static bool attr_done = false;   // per instantiation
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                kLds) != hipSuccess)
+            return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
+        attr_done = true;
+    }
+    const int ntiles = (g.M + BM - 1) / BM;
+    const int grid = ntiles < 256 ? ntiles : 256;
+    hipLaunchKernelGGL(mlp_kernel<PROJ>, dim3(grid), dim3(kThreads), kLds, s, g);
+    return check_launch("mlp_kernel");
+}
+}  // namespace
+
 int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
               int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s) {
     MlpArgs g;
+    g.A0 = nullptr; g.lda0 = 0; g.Wp = nullptr; g.bp = nullptr; g.gamma2 = nullptr; g.beta2 = nullptr;
     g.A = reinterpret_cast<const u16*>(a); g.lda = lda;
     g.W1 = reinterpret_cast<const u16*>(w1); g.b1 = b1;
     g.W2 = reinterpret_cast<const u16*>(w2); g.b2 = b2;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta;
     g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps; g.M = M;
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kLds) !=
-            hipSuccess)
-            return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
-        attr_done = true;
-    }
-    const int ntiles = (M + BM - 1) / BM;
-    const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(mlp_kernel, dim3(grid), dim3(kThreads), kLds, s, g);
-    return check_launch("mlp_kernel");
+    return launch_mlp<false>(g, s);
+}
+
+// The rest of a transformer block after attention in one kernel (vision_transformer.py:110-111):
+//   x += att Wp^T + bp ;  ln_mid = LayerNorm2(x) ;  x += fc2(gelu(fc1(ln_mid))) ;  ln = LayerNorm(x)
+// ln_mid (M, 384) bf16 is scratch in memory (written and read back by the same workgroup); ln may be the
+// same buffer, or null.
+int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, const float* gamma2, const float* beta2,
+                void* ln_mid, int64_t ld_mid, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+                int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s) {
+    MlpArgs g;
+    g.A0 = reinterpret_cast<const u16*>(att); g.lda0 = lda0;
+    g.Wp = reinterpret_cast<const u16*>(wp); g.bp = bp; g.gamma2 = gamma2; g.beta2 = beta2;
+    g.A = reinterpret_cast<const u16*>(ln_mid); g.lda = ld_mid;
+    g.W1 = reinterpret_cast<const u16*>(w1); g.b1 = b1;
+    g.W2 = reinterpret_cast<const u16*>(w2); g.b2 = b2;
+    g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta;
+    g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps; g.M = M;
+    return launch_mlp<true>(g, s);
 }
 
 }  // namespace equss
@@ -356,4 +509,23 @@ extern "C" int equss_mlp_resid_ln_bf16(const void* a, int64_t lda, const void* w
         return equss::fail(EQUSS_E_ALIGN, "mlp_resid_ln: operands must be 16-byte aligned with padded leading dimensions");
     return equss::mlp_fused(a, lda, w1, b1, w2, b2, x, ldx, gamma, beta, ln_out, ld_ln, M, eps,
                             reinterpret_cast<hipStream_t>(stream));
+}
+
+// x += att Wp^T + bp; ln_mid = LayerNorm2(x); x += fc2(gelu(fc1(ln_mid))); ln_out = LayerNorm(x) (or null).
+extern "C" int equss_block_tail_bf16(const void* att, int64_t ld_att, const void* wp, const float* bp, const float* gamma2,
+                                     const float* beta2, void* ln_mid, int64_t ld_mid, const void* w1, const float* b1,
+                                     const void* w2, const float* b2, float* x, int64_t ldx, const float* gamma,
+                                     const float* beta, void* ln_out, int64_t ld_ln, int M, int C_, int hidden, float eps,
+                                     void* stream) {
+    if (!att || !wp || !bp || !gamma2 || !beta2 || !ln_mid || !w1 || !b1 || !w2 || !b2 || !x || (ln_out && (!gamma || !beta)))
+        return equss::fail(EQUSS_E_NULL, "block_tail: null pointer argument");
+    if (M <= 0) return equss::fail(EQUSS_E_SHAPE, "block_tail: M=%d must be positive", M);
+    if (!equss::mlp_fused_supports(C_, hidden))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "block_tail: C=%d hidden=%d (384 and 1536 only)", C_, hidden);
+    if (ld_att < C_ || ld_mid < C_ || ldx < C_ || (ln_out && ld_ln < C_) || (ld_att % 8) || (ld_mid % 8) || (ldx % 4) ||
+        (ld_ln % 8) || ((uintptr_t)att % 16) || ((uintptr_t)wp % 16) || ((uintptr_t)ln_mid % 16) || ((uintptr_t)w1 % 16) ||
+        ((uintptr_t)w2 % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
+        return equss::fail(EQUSS_E_ALIGN, "block_tail: operands must be 16-byte aligned with padded leading dimensions");
+    return equss::block_fused(att, ld_att, wp, bp, gamma2, beta2, ln_mid, ld_mid, w1, b1, w2, b2, x, ldx, gamma, beta, ln_out,
+                              ld_ln, M, eps, reinterpret_cast<hipStream_t>(stream));
 }

@@ -8,6 +8,9 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
 int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s);
 bool gemm8_resid_ln_supports(int N, int K);
 bool mlp_fused_supports(int C, int hidden);
+int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, const float* gamma2, const float* beta2,
+                void* ln_mid, int64_t ld_mid, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
+                int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
 int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
               int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
 int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
@@ -271,6 +274,35 @@ int mlp_balanced(const void* a, int64_t lda, const void* w1, const float* b1, co
     return equss::check_launch("layernorm_rowtile_kernel");
 }
 
+// Everything after attention for C = 384: the fused block kernel on the whole rounds of tiles, the trailing
+// rows through the small-tile routes of the projection and of the MLP (same bits either way).
+int block_balanced(const void* att, const void* wp, const float* bp, const float* gamma2, const float* beta2, void* ln_mid,
+                   const void* w1, const float* b1, const void* w2, const float* b2, float* x, const float* gamma,
+                   const float* beta, void* ln, void* hid, int M, float eps, hipStream_t s) {
+    const int C = 384, H = 1536;
+    const int tiles = (M + 127) / 128, rounds = tiles / 256, rem = tiles % 256;
+    const bool split = rounds >= 1 && rem != 0 && rem <= g_mlp_tail_max && hid;
+    const int m_main = split ? rounds * 256 * 128 : M, m_tail = M - m_main;
+    int rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s);
+    if (rc || m_tail == 0) return rc;
+    const u16* att_tail = reinterpret_cast<const u16*>(att) + (size_t)m_main * C;
+    u16* mid_tail = reinterpret_cast<u16*>(ln_mid) + (size_t)m_main * C;
+    float* x_tail = x + (size_t)m_main * C;
+    rc = equss::gemm_bf16(att_tail, C, wp, C, bp, x_tail, C, m_tail, C, C, EQUSS_EPI_RESID_F32, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, C, gamma2, beta2, mid_tail, C,
+                       m_tail, eps);
+    rc = equss::check_launch("layernorm_rowtile_kernel");
+    if (rc) return rc;
+    rc = equss::gemm_bf16(mid_tail, C, w1, C, b1, hid, H, m_tail, H, C, EQUSS_EPI_GELU_BF16, s);
+    if (rc) return rc;
+    rc = equss::gemm_bf16(hid, H, w2, H, b2, x_tail, C, m_tail, C, H, EQUSS_EPI_RESID_F32, s);
+    if (rc || !ln) return rc;
+    hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, C, gamma, beta,
+                       reinterpret_cast<u16*>(ln) + (size_t)m_main * C, C, m_tail, eps);
+    return equss::check_launch("layernorm_rowtile_kernel");
+}
+
 int patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls, const float* pos,
                  float* x, void* ws, int B, int H, int W, int P, int C, hipStream_t s) {
     PatchWs w = carve_patch(ws, B, H, W, P, C);
@@ -325,7 +357,7 @@ extern "C" int equss_patch_tokens(const float* img, const void* w_patch, const f
     return patch_tokens(img, w_patch, b_patch, cls, pos, x, workspace, B, H, W, P, C, reinterpret_cast<hipStream_t>(stream));
 }
 
-int g_mlp_fused = 1;   // developer switch: 0 = fc1 and fc2 as two GEMM launches
+int g_mlp_fused = 2;   // developer switch: 2 = proj + MLP in one kernel, 1 = MLP in one kernel, 0 = one launch per GEMM
 extern "C" void equss_dev_mlp_fused(int on) { g_mlp_fused = on; }
 extern "C" void equss_dev_mlp_tail_max(int n) { g_mlp_tail_max = n; }
 
@@ -378,6 +410,11 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         }
         EQUSS_STEP(EQUSS_K_GEMM_QKV, equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))
         EQUSS_STEP(EQUSS_K_ATTENTION, equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))
+        if (fuse && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
+            const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
+            EQUSS_STEP(EQUSS_K_BLOCK_TAIL, block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s))
+            continue;
+        }
         if (fuse) {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, resid_ln_balanced(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
         } else {

@@ -18,7 +18,7 @@ EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3, 4
 EXPORTED_SYMBOLS = [
     "equss_abi_version", "equss_last_error", "equss_profile_enable", "equss_profile_read",
     "equss_pq_workspace_bytes", "equss_pq_assign", "equss_pq_prob",
-    "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_attention_bf16",
+    "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_block_tail_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
     "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
@@ -74,6 +74,9 @@ def _declare(lib):
     lib.equss_mlp_resid_ln_bf16.restype = c_int
     lib.equss_mlp_resid_ln_bf16.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64,
                                             c_int, c_int, c_int, c_f, c_vp]
+    lib.equss_block_tail_bf16.restype = c_int
+    lib.equss_block_tail_bf16.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                          c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_f, c_vp]
     lib.equss_attention_bf16.restype = c_int
     lib.equss_attention_bf16.argtypes = [c_vp, c_vp, c_int, c_int, c_int, c_f, c_vp]
     lib.equss_patch_workspace_bytes.restype = c_sz
@@ -156,7 +159,7 @@ def _workspace(device, nbytes, tag):
 
 
 KERNEL_CLASSES = ["patch", "layernorm", "gemm_qkv", "attention", "gemm_proj", "gemm_fc1", "gemm_fc2",
-                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign", "probe_table", "probe_pixels", "mlp_fused"]
+                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign", "probe_table", "probe_pixels", "mlp_fused", "block_tail"]
 
 
 def profile_enable(max_pairs):
@@ -296,6 +299,23 @@ def mlp_resid_ln_bf16(a, w1, b1, w2, b2, x, gamma=None, beta=None, eps=1e-6, wan
                                      float(eps), _stream(a))
     _check(rc, "equss_mlp_resid_ln_bf16")
     return ln
+
+
+def block_tail_bf16(att, wp, bp, gamma2, beta2, w1, b1, w2, b2, x, gamma=None, beta=None, eps=1e-6, want_ln=True):
+    """x += att @ wp.T + bp; x += gelu(LN2(x) @ w1.T + b1) @ w2.T + b2 (fp32, in place); returns
+    (LayerNorm2 of the intermediate x, LayerNorm(x) * gamma + beta or None), both bf16."""
+    lib = load_library()
+    _need_cuda(att, wp, bp, gamma2, beta2, w1, b1, w2, b2, x, gamma, beta)
+    m, c = att.shape
+    hidden = w1.shape[0]
+    mid = torch.empty((m, c), dtype=torch.bfloat16, device=att.device)
+    ln = torch.empty((m, c), dtype=torch.bfloat16, device=att.device) if want_ln else None
+    rc = lib.equss_block_tail_bf16(_ptr(att), att.stride(0), _ptr(wp), _ptr(bp), _ptr(gamma2), _ptr(beta2), _ptr(mid),
+                                   mid.stride(0), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(x), x.stride(0), _ptr(gamma),
+                                   _ptr(beta), _ptr(ln), c if ln is None else ln.stride(0), m, c, hidden, float(eps),
+                                   _stream(att))
+    _check(rc, "equss_block_tail_bf16")
+    return mid, ln
 
 
 def attention_bf16(qkv, batch, tokens, heads, scale, out=None):

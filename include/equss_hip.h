@@ -81,7 +81,8 @@ enum {
     EQUSS_K_PROBE_TABLE = 11,  /* low-resolution probe products + neighbour Gram entries */
     EQUSS_K_PROBE_PIXELS = 12, /* per-pixel interpolation, arg-max, losses */
     EQUSS_K_MLP_FUSED = 13,    /* fc1 + GELU + fc2 + residual + LayerNorm in one kernel */
-    EQUSS_K_COUNT = 14
+    EQUSS_K_BLOCK_TAIL = 14,   /* proj + residual + LayerNorm2 + MLP + residual + LayerNorm in one kernel */
+    EQUSS_K_COUNT = 15
 };
 int equss_profile_enable(int max_pairs);
 int equss_profile_read(double* ms, int64_t* launches, int reset);
@@ -160,6 +161,19 @@ int equss_gemm_resid_ln_bf16(const void* A, int64_t lda, const void* W, int64_t 
 int equss_mlp_resid_ln_bf16(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2,
                             const float* b2, float* x, int64_t ldx, const float* gamma, const float* beta,
                             void* ln_out, int64_t ld_ln, int M, int C, int hidden, float eps, void* stream);
+
+/* Everything of a transformer block after its attention, in one kernel (vision_transformer.py:110-111
+ * with :58-64):
+ *   x += att * Wp^T + bp ;  ln_mid = LayerNorm2(x) ;  x += gelu(ln_mid * W1^T + b1) * W2^T + b2 ;
+ *   ln_out = LayerNorm(x) * gamma + beta in bf16 (or NULL).
+ * att (M, C) bf16 = attention output; ln_mid (M, C) bf16 is scratch that the kernel writes and reads back
+ * (ln_out may be the same buffer).  Same restrictions and the same bits as equss_gemm_resid_ln_bf16
+ * followed by equss_mlp_resid_ln_bf16. */
+int equss_block_tail_bf16(const void* att, int64_t ld_att, const void* wp, const float* bp, const float* gamma2,
+                          const float* beta2, void* ln_mid, int64_t ld_mid, const void* w1, const float* b1,
+                          const void* w2, const float* b2, float* x, int64_t ldx, const float* gamma,
+                          const float* beta, void* ln_out, int64_t ld_ln, int M, int C, int hidden, float eps,
+                          void* stream);
 
 /* Multi-head self-attention softmax(q k^T * scale) v without materialising the (N x N) matrix
  * (vision_transformer.py:81-88; the attention matrix it returns is discarded by

@@ -261,3 +261,32 @@ def test_mlp_fused_equals_the_two_gemm_route(m, native, dev):
     x_n = d(x0.clone())
     assert native.mlp_resid_ln_bf16(d(a), d(w1), d(b1), d(w2), d(b2), x_n, want_ln=False) is None
     assert torch.equal(x_n, x_f)
+
+
+@pytest.mark.parametrize("m", [1, 128 * 3 + 77, 128 * 300 + 5])
+def test_block_tail_fused_equals_separate_launches(m, native, dev):
+    """proj + residual + LayerNorm2 + MLP + residual + LayerNorm in one kernel against
+    equss_gemm_resid_ln_bf16 followed by equss_mlp_resid_ln_bf16: bit for bit."""
+    g = _rng(1000 + m)
+    c, hid = 384, 1536
+    rnd = lambda *shape, s=1.0: torch.from_numpy((s * g.standard_normal(shape)).astype(np.float32))   # noqa: E731
+    att = _bf(rnd(m, c))
+    wp, bp = _bf(rnd(c, c, s=1 / math.sqrt(c))), rnd(c, s=0.3)
+    w1, b1 = _bf(rnd(hid, c, s=1 / math.sqrt(c))), rnd(hid, s=0.3)
+    w2, b2 = _bf(rnd(c, hid, s=1 / math.sqrt(hid))), rnd(c, s=0.3)
+    x0 = rnd(m, c)
+    g2, be2 = 1 + rnd(c, s=0.1), rnd(c, s=0.1)
+    g1, be1 = 1 + rnd(c, s=0.1), rnd(c, s=0.1)
+    d = lambda t: t.to(dev)   # noqa: E731
+    x_f = d(x0.clone())
+    mid_f, ln_f = native.block_tail_bf16(d(att), d(wp), d(bp), d(g2), d(be2), d(w1), d(b1), d(w2), d(b2), x_f, d(g1), d(be1))
+    x_u = d(x0.clone())
+    mid_u = native.gemm_resid_ln_bf16(d(att), d(wp), d(bp), x_u, d(g2), d(be2), 1e-6)
+    ln_u = native.mlp_resid_ln_bf16(mid_u, d(w1), d(b1), d(w2), d(b2), x_u, d(g1), d(be1), 1e-6)
+    torch.cuda.synchronize()
+    assert torch.equal(mid_f, mid_u)
+    assert torch.equal(x_f, x_u)
+    assert torch.equal(ln_f, ln_u)
+    x_n = d(x0.clone())
+    _, none = native.block_tail_bf16(d(att), d(wp), d(bp), d(g2), d(be2), d(w1), d(b1), d(w2), d(b2), x_n, want_ln=False)
+    assert none is None and torch.equal(x_n, x_f)
