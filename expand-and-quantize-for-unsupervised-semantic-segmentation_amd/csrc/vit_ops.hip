@@ -357,9 +357,11 @@ extern "C" int equss_patch_tokens(const float* img, const void* w_patch, const f
     return patch_tokens(img, w_patch, b_patch, cls, pos, x, workspace, B, H, W, P, C, reinterpret_cast<hipStream_t>(stream));
 }
 
+int g_fuse_min_tiles = 384;
 int g_mlp_fused = 2;   // developer switch: 2 = proj + MLP in one kernel, 1 = MLP in one kernel, 0 = one launch per GEMM
 extern "C" void equss_dev_mlp_fused(int on) { g_mlp_fused = on; }
 extern "C" void equss_dev_mlp_tail_max(int n) { g_mlp_tail_max = n; }
+extern "C" void equss_dev_fuse_min_tiles(int n) { g_fuse_min_tiles = n; }
 
 extern "C" size_t equss_vit_workspace_bytes(const EqussVit* vit, int B, int H, int W) {
     if (!vit || B <= 0 || H <= 0 || W <= 0 || vit->patch <= 0) return 0;
@@ -410,7 +412,9 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         }
         EQUSS_STEP(EQUSS_K_GEMM_QKV, equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))
         EQUSS_STEP(EQUSS_K_ATTENTION, equss::attention_bf16(w.qkv, w.att, B, N, heads, scale, s))
-        if (fuse && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
+        // (below ~1.5 rounds of 128-row tiles on the 256 CUs the one-launch-per-GEMM route spreads the work better)
+        const bool big = (rows + 127) / 128 >= g_fuse_min_tiles;
+        if (fuse && big && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
             EQUSS_STEP(EQUSS_K_BLOCK_TAIL, block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s))
             continue;
@@ -421,7 +425,7 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, equss::gemm_bf16(w.att, C, k.proj_w, C, k.proj_b, w.x, C, rows, C, C, EQUSS_EPI_RESID_F32, s))
             EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln2_g, k.ln2_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
         }
-        if (fuse && g_mlp_fused && equss::mlp_fused_supports(C, 4 * C)) {
+        if (fuse && big && g_mlp_fused && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
             EQUSS_STEP(EQUSS_K_MLP_FUSED, mlp_balanced(w.ln, C, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, C, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, C, w.hid, rows, 1e-6f, s))
             continue;

@@ -456,6 +456,7 @@ class DIONPQGO(nn.Module):
         self._head_key = None
         # eval forward: image ranges of a batch run on this many HIP streams (1 = everything on the caller's)
         self.eval_streams = 2
+        self.eval_stream_min_images = 4   # per stream; smaller ranges leave the chip emptier than one launch does
         self._streams = None
 
     # -- expansion head weights for the HIP GEMMs ---------------------------------------------------
@@ -556,7 +557,7 @@ class DIONPQGO(nn.Module):
         p = self.extractor.patch_size
         gh, gw = h // p, w // p
         if not self.training:
-            if self.eval_streams > 1 and img.is_cuda and b >= self.eval_streams:
+            if self.eval_streams > 1 and img.is_cuda and b >= self.eval_streams * self.eval_stream_min_images:
                 return self._forward_eval_streams(img)
             code_rows, _ = self._code_rows(img)
             code = _nchw_of(code_rows, b, gh, gw)

@@ -77,6 +77,7 @@ def test_streamed_eval_forward_equals_single_stream(pkg, dev):
     img = pkg.synth.synth_images(7, 96, 64, seed=21).to(dev)
     with torch.no_grad():
         m.model.eval_streams = 1
+        m.model.eval_stream_min_images = 1
         ref = m.model(img=img)
         for k in (2, 3):
             m.model.eval_streams = k
