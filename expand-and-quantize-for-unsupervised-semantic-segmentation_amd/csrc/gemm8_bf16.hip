@@ -91,7 +91,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
     constexpr int RP = (kStageBytes / NW >= 32 * ROWSTRIDE && TM >= 32) ? 32 : 16;
     constexpr int OCH = TN * 2 / 16;
     constexpr int PER_LANE = RP * OCH / 64;
-    constexpr int NST = (EPI == EQUSS_EPI_F32 || EPI == EPI_RESID_LN) ? 0 : PER_LANE * (TM / RP);
+    constexpr int NST = (EPI == EQUSS_EPI_F32 || EPI == EPI_RESID_LN || EPI == EQUSS_EPI_RESID_F32) ? 0 : PER_LANE * (TM / RP);
     static_assert((S - 1) * PW + NST <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -189,19 +189,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
         const int m0 = (logical / g.ntn) * BM;
         const int n0 = (logical % g.ntn) * BN;
         f32x4 acc[NT][MT];  // element j <-> output column n + j
-        if constexpr (EPI == EPI_RESID_LN) {
+        if constexpr (EPI == EPI_RESID_LN || EPI == EQUSS_EPI_RESID_F32) {
             // Start the accumulators from x + bias: the residual tile is fetched while the first K step
             // is being waited for, straight into the accumulator registers, and the epilogue is left
-            // with stores only.
+            // with stores only.  (EPI_RESID_LN: x = g.x, one column tile; EPI_RESID_F32: x = out.)
+            const float* xs = EPI == EPI_RESID_LN ? g.x : reinterpret_cast<const float*>(g.out);
+            const int64_t ldxs = EPI == EPI_RESID_LN ? g.ldx : g.ldo;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int n = wn * TN + nt * 16 + fq * 4;
+                const int n = n0 + wn * TN + nt * 16 + fq * 4;
                 const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + n);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = m0 + wm * TM + mt * 16 + fr;
                     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
+                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(xs + (size_t)m * ldxs + n);
                     o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
                     acc[nt][mt] = o;
                 }
@@ -348,8 +350,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                     asm volatile("" ::: "memory");
                 }
             }
-        } else if constexpr (EPI == EQUSS_EPI_F32) {
-            // lane owns out[m][n .. n+3] as one 16-byte store
+        } else if constexpr (EPI == EQUSS_EPI_F32 || EPI == EQUSS_EPI_RESID_F32) {
+            // lane owns out[m][n .. n+3] as one 16-byte store (EPI_RESID_F32: bias and the old value are already in)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = n0 + wn * TN + nt * 16 + fq * 4;
@@ -359,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                     const int m = m0 + wm * TM + mt * 16 + fr;
                     if (m >= g.M) continue;
                     f32x4 v = acc[nt][mt];
-                    v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                    if constexpr (EPI == EQUSS_EPI_F32) { v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w; }
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(g.out) + (size_t)m * g.ldo + n) = v;
                 }
             }
@@ -485,7 +487,7 @@ int launch(Gemm8Args& g, hipStream_t s) {
 namespace equss {
 
 bool gemm8_supports(int N, int K, int epilogue) {
-    return (N % 384 == 0 || N % 256 == 0) && K % 64 == 0 && epilogue != EQUSS_EPI_RESID_F32;
+    return (N % 384 == 0 || N % 256 == 0) && K % 64 == 0;
 }
 
 int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
@@ -500,6 +502,7 @@ int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const flo
         case EQUSS_EPI_GELU_BF16: return launch<EQUSS_EPI_GELU_BF16>(g, s);
         case EQUSS_EPI_RELU_BF16: return launch<EQUSS_EPI_RELU_BF16>(g, s);
         case EQUSS_EPI_F32: return launch<EQUSS_EPI_F32>(g, s);
+        case EQUSS_EPI_RESID_F32: return launch<EQUSS_EPI_RESID_F32>(g, s);
         default: return fail(EQUSS_E_UNSUPPORTED, "gemm8: unsupported epilogue %d", epilogue);
     }
 }

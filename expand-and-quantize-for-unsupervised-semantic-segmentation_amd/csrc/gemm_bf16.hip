@@ -272,7 +272,9 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
     if (lda < K || ldw < K || ldo < N || (lda % 8) || (ldw % 8) || (ldo % 4) || ((uintptr_t)A % 16) ||
         ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (bias && ((uintptr_t)bias % 16)))
         return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
-    if (g_variant == 3 && gemm8_supports(N, K, epilogue))
+    // (the in-place residual update keeps the small tiles for short M: that is what the trailing-row
+    // routes of the fused kernels want)
+    if (g_variant == 3 && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
         return gemm8_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
     GemmArgs g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;

@@ -290,3 +290,27 @@ def test_block_tail_fused_equals_separate_launches(m, native, dev):
     x_n = d(x0.clone())
     _, none = native.block_tail_bf16(d(att), d(wp), d(bp), d(g2), d(be2), d(w1), d(b1), d(w2), d(b2), x_n, want_ln=False)
     assert none is None and torch.equal(x_n, x_f)
+
+
+@pytest.mark.parametrize("shape", [(20000, 768, 768), (17000, 768, 3072), (40000, 384, 1536)])
+def test_residual_gemm_large_tile_route_equals_small_tile_route(shape, native, dev):
+    """out += a w^T + bias: the large-tile kernel (long M) and the 128 x 128 kernel (short M, trailing
+    rows) apply the same fp32 operations in the same order, so a row's bits do not depend on the route."""
+    import ctypes
+    m, n, k = shape
+    g = _rng(m + n)
+    a = _bf(torch.from_numpy(g.standard_normal((m, k)).astype(np.float32))).to(dev)
+    w = _bf(torch.from_numpy((g.standard_normal((n, k)) / math.sqrt(k)).astype(np.float32))).to(dev)
+    bias = torch.from_numpy(g.standard_normal(n).astype(np.float32)).to(dev)
+    x0 = torch.from_numpy(g.standard_normal((m, n)).astype(np.float32)).to(dev)
+    lib = native.load_library()
+    big = native.gemm_bf16(a, w, bias, 4, out=x0.clone())
+    lib.equss_dev_gemm_variant(ctypes.c_int(0))
+    try:
+        small = native.gemm_bf16(a, w, bias, 4, out=x0.clone())
+    finally:
+        lib.equss_dev_gemm_variant(ctypes.c_int(3))
+    torch.cuda.synchronize()
+    assert torch.equal(big, small)
+    ref = x0.double() + a.double() @ w.double().t() + bias.double()
+    assert float((big.double() - ref).abs().max()) < 5e-4
