@@ -8,7 +8,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-CLASS = [("mlp_kernel", "mlp_fused"), ("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
+CLASS = [("mlp_kernel<true", "block_tail"), ("mlp_kernel", "mlp_fused"), ("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
          ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"),
          ("layernorm_rowtile_kernel", "layernorm_tail(proj,fc2)"), ("layernorm_kernel", "layernorm"),
          ("gemm8_kernel<1,", "gemm_fc1"), ("gemm8_kernel<0,", "gemm_bf16out"), ("gemm8_kernel<2,", "head_gemm1"),
@@ -30,7 +30,7 @@ for sub, suffix in (("trace", ""), ("trace2", "_2streams")):
     found = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if not found:
         continue
-    rows = list(csv.DictReader(open(found[0])))
+    rows = list(csv.DictReader(open(max(found, key=os.path.getmtime))))   # (gpurun merges runs: keep the newest)
     with open(os.path.join(out, f"{tag}_kernel_stats{suffix}.csv"), "w") as f:
         w = csv.writer(f)
         w.writerow(["kernel", "class", "calls", "total_ms", "avg_us", "percent"])
@@ -43,7 +43,7 @@ for sub, suffix in (("trace", ""), ("trace2", "_2streams")):
 
 traffic = collections.defaultdict(lambda: {"fetch_raw_kb": 0.0, "write_raw_kb": 0.0, "launches_f": 0, "launches_w": 0})
 for counter, sub, fld, cnt in (("FETCH_SIZE", "fetch", "fetch_raw_kb", "launches_f"), ("WRITE_SIZE", "write", "write_raw_kb", "launches_w")):
-    for f in glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")):
+    for f in sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
@@ -70,6 +70,7 @@ flat = {"attention": summary.get("attention", {}).get("hbm_bytes_per_launch"),
         "pq_assign": summary.get("pq_assign", {}).get("hbm_bytes_per_launch"),
         "gemm_fc1": summary.get("gemm_fc1", {}).get("hbm_bytes_per_launch"),
         "mlp_fused": summary.get("mlp_fused", {}).get("hbm_bytes_per_launch"),
+        "block_tail": summary.get("block_tail", {}).get("hbm_bytes_per_launch"),
         "gemm_qkv": summary.get("gemm_bf16out", {}).get("hbm_bytes_per_launch")}
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(flat, f, indent=1, sort_keys=True)
