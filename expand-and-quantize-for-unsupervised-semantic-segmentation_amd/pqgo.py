@@ -203,6 +203,54 @@ def _torch_normalize(z, weight, normalize):
     raise ValueError(f"Unsupported normalize type {normalize}")
 
 
+class _PQStraightThrough(torch.autograd.Function):
+    """Training-pass quantisation for l2-normalised codes with raw codeword gather (dino_pqgo.py:613-690):
+        zn = z / |z| ;  emb = books[idx] ;  vq = mean_p(book * mse(emb, zn.detach()) + beta * mse(zn, emb.detach()))
+        zq = zn + (emb - zn).detach()
+    Forward = the eval path's HIP kernel (indices, gathered rows, squared-error sums in one pass);
+    backward = the closed form, a handful of elementwise passes and ONE index_add into the codebooks,
+    instead of autograd through ~15 elementwise ops on (rows, D) tensors:
+        d zn   = g_zq + g_vq * 2 beta (zn - emb) / (n d P)          d z = (d zn - zn <zn, d zn>) / |z|
+        d emb  = g_vq * 2 book (emb - zn) / (n d P)                  d books[p, k] = sum over rows with idx = k
+    Returns (zq rows, vq-loss, idx)."""
+
+    @staticmethod
+    def forward(ctx, rows, books, beta, book):
+        num_pq, k, d = books.shape
+        n = rows.shape[0]
+        idx, emb, loss_sum = native.pq_assign(rows, books, "l2", False)
+        vq = ((book + beta) * (loss_sum / float(n * d))).mean()
+        ctx.save_for_backward(rows, emb, idx)
+        ctx.meta = (num_pq, k, d, float(beta), float(book))
+        ctx.mark_non_differentiable(idx)
+        return emb, vq, idx
+
+    @staticmethod
+    def backward(ctx, g_zq, g_vq, _g_idx):
+        rows, emb, idx = ctx.saved_tensors
+        num_pq, k, d, beta, book = ctx.meta
+        n = rows.shape[0]
+        z3 = rows.reshape(n, num_pq, d)
+        norm = z3.norm(dim=-1, keepdim=True).clamp_min(1e-12)     # F.normalize's eps
+        zn = z3 / norm
+        diff = zn - emb.reshape(n, num_pq, d)
+        scale = g_vq * (2.0 / float(n * d * num_pq))
+        g_books = None
+        if ctx.needs_input_grad[1]:
+            flat = (idx + torch.arange(num_pq, device=idx.device).unsqueeze(1) * k).t().reshape(-1)   # (n * P,)
+            g_books = torch.zeros(num_pq * k, d, dtype=rows.dtype, device=rows.device)
+            g_books.index_add_(0, flat, (diff * (-book * scale)).reshape(n * num_pq, d))
+            g_books = g_books.reshape(num_pq, k, d)
+        g_rows = None
+        if ctx.needs_input_grad[0]:
+            g_zn = diff.mul_(beta * scale)
+            if g_zq is not None:
+                g_zn += g_zq.reshape(n, num_pq, d)
+            proj = (zn * g_zn).sum(dim=-1, keepdim=True)
+            g_rows = (g_zn.addcmul_(zn, proj, value=-1.0) / norm).reshape(n, num_pq * d)
+        return g_rows, g_books, None, None
+
+
 def _quantize_rows(rows, books, normalize, beta, book, training, vq_counts, gather_normalized=False,
                    use_restart=False, quantizers=None):
     """Shared core of Codebook / ProductQuantizerWrapper.
@@ -214,6 +262,9 @@ def _quantize_rows(rows, books, normalize, beta, book, training, vq_counts, gath
         idx, zq, loss_sum = native.pq_assign(rows.detach(), books.detach(), normalize, gather_normalized)
         per_pq = loss_sum / float(n * d)                       # mse per sub-space
         output["vq-loss"] = ((book + beta) * per_pq).mean()    # dino_pqgo.py:685-687 then :771-772
+    elif normalize == "l2" and not gather_normalized and rows.is_cuda:
+        zq, vq, idx = _PQStraightThrough.apply(rows, books, beta, book)
+        output["vq-loss"] = vq
     else:
         idx, _, _ = native.pq_assign(rows.detach(), books.detach(), normalize, gather_normalized,
                                      want_zq=False, want_loss=False)

@@ -142,3 +142,30 @@ def test_screened_search_equals_exact_search(kind, rows, k, native, oracle, dev)
     # the screened kernel is deterministic run to run, loss included
     idx_2, zq_2, loss_2 = native.pq_assign(code.to(dev), books.to(dev))
     assert torch.equal(idx_2, idx_s) and torch.equal(zq_2, zq_s) and torch.equal(loss_2, loss_s)
+
+
+def test_training_quantiser_gradients_match_autograd(pkg, dev):
+    """The closed-form backward of the training-pass quantiser against autograd through the stock
+    formulation (dino_pqgo.py:613-690) on the same indices: loss, straight-through output, gradients
+    w.r.t. the code rows and the codebooks."""
+    import torch.nn.functional as F
+    torch.manual_seed(2)
+    n, num_pq, k, d = 3000, 8, 256, 128
+    rows = torch.randn(n, num_pq * d, device=dev).requires_grad_(True)
+    books = (torch.rand(num_pq, k, d, device=dev) * 2 - 1).requires_grad_(True)
+    beta, book = 0.25, 1.0
+    g_out = torch.randn(n, num_pq * d, device=dev)
+    zq, vq, idx = pkg.pqgo._PQStraightThrough.apply(rows, books, beta, book)
+    got = torch.autograd.grad((zq * g_out).sum() + 3.0 * vq, (rows, books))
+    z3 = rows.reshape(n, num_pq, d)
+    zn = F.normalize(z3, dim=-1)
+    emb = torch.gather(books, 1, idx.unsqueeze(-1).expand(num_pq, n, d)).permute(1, 0, 2)
+    cb = ((emb - zn.detach()) ** 2).mean(dim=(0, 2))
+    commit = ((zn - emb.detach()) ** 2).mean(dim=(0, 2))
+    vq_ref = (book * cb + beta * commit).mean()
+    zq_ref = (zn + (emb - zn).detach()).reshape(n, num_pq * d)
+    ref = torch.autograd.grad((zq_ref * g_out).sum() + 3.0 * vq_ref, (rows, books))
+    assert abs(float(vq.detach()) - float(vq_ref.detach())) < 1e-5 * abs(float(vq_ref.detach()))
+    assert float((zq - zq_ref).abs().max()) < 1e-6
+    for name, a, b in zip(("rows", "books"), got, ref):
+        assert float((a - b).norm() / b.norm()) < 1e-5, name
