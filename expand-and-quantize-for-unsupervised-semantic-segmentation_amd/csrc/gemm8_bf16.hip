@@ -33,9 +33,15 @@ struct Gemm8Args {
     const float* gamma; const float* beta;
     u16* ln; int64_t ld_ln;
     float eps;
+    const float* pos; int group;   // EPI_PATCH_LN
 };
 
 constexpr int EPI_RESID_LN = 100;  // internal epilogue id: x += acc + bias; ln = LayerNorm(x)
+// internal epilogue id: token assembly of the patch embedding (vision_transformer.py:205-209) with the first
+// LayerNorm: output row m (patch m % group of image m / group) goes to token row m + m / group + 1,
+// x = pos[1 + m % group] + bias + acc, ln = LayerNorm(x)
+constexpr int EPI_PATCH_LN = 101;
+constexpr bool row_ln(int e) { return e == EPI_RESID_LN || e == EPI_PATCH_LN; }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds(
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
     constexpr int RP = (kStageBytes / NW >= 32 * ROWSTRIDE && TM >= 32) ? 32 : 16;
     constexpr int OCH = TN * 2 / 16;
     constexpr int PER_LANE = RP * OCH / 64;
-    constexpr int NST = (EPI == EQUSS_EPI_F32 || EPI == EPI_RESID_LN || EPI == EQUSS_EPI_RESID_F32) ? 0 : PER_LANE * (TM / RP);
+    constexpr int NST = (EPI == EQUSS_EPI_F32 || row_ln(EPI) || EPI == EQUSS_EPI_RESID_F32) ? 0 : PER_LANE * (TM / RP);
     static_assert((S - 1) * PW + NST <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -159,7 +165,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
     float* gamma_s = bias_s + g.N;       // EPI_RESID_LN only (N == BN there)
     float* beta_s = gamma_s + BN;
     float2* red_s = reinterpret_cast<float2*>(beta_s + BN);  // BM rows x WN partial (sum, sum of squares)
-    if constexpr (EPI == EPI_RESID_LN) {
+    if constexpr (row_ln(EPI)) {
         for (int i = tid; i < BN; i += kThreads) {
             gamma_s[i] = g.ln ? g.gamma[i] : 1.f;
             beta_s[i] = g.ln ? g.beta[i] : 0.f;
@@ -189,12 +195,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
         const int m0 = (logical / g.ntn) * BM;
         const int n0 = (logical % g.ntn) * BN;
         f32x4 acc[NT][MT];  // element j <-> output column n + j
-        if constexpr (EPI == EPI_RESID_LN || EPI == EQUSS_EPI_RESID_F32) {
+        if constexpr (row_ln(EPI) || EPI == EQUSS_EPI_RESID_F32) {
             // Start the accumulators from x + bias: the residual tile is fetched while the first K step
             // is being waited for, straight into the accumulator registers, and the epilogue is left
-            // with stores only.  (EPI_RESID_LN: x = g.x, one column tile; EPI_RESID_F32: x = out.)
-            const float* xs = EPI == EPI_RESID_LN ? g.x : reinterpret_cast<const float*>(g.out);
-            const int64_t ldxs = EPI == EPI_RESID_LN ? g.ldx : g.ldo;
+            // with stores only.  (EPI_RESID_LN: x = g.x, one column tile; EPI_RESID_F32: x = out;
+            // EPI_PATCH_LN: the position embedding of the row's token takes the place of x.)
+            const float* xs = EPI == EPI_PATCH_LN ? g.pos : EPI == EPI_RESID_LN ? g.x : reinterpret_cast<const float*>(g.out);
+            const int64_t ldxs = EPI == EPI_PATCH_LN ? g.N : EPI == EPI_RESID_LN ? g.ldx : g.ldo;
+            size_t src_row[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wm * TM + mt * 16 + fr;
+                src_row[mt] = EPI == EPI_PATCH_LN ? (size_t)(1 + m % g.group) : (size_t)m;
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = n0 + wn * TN + nt * 16 + fq * 4;
@@ -203,7 +216,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = m0 + wm * TM + mt * 16 + fr;
                     f32x4 o = {0.f, 0.f, 0.f, 0.f};
-                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(xs + (size_t)m * ldxs + n);
+                    if (m < g.M) o = *reinterpret_cast<const f32x4*>(xs + src_row[mt] * ldxs + n);
                     o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
                     acc[nt][mt] = o;
                 }
@@ -284,23 +297,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
         }
         }
         // ---- epilogue (stores only) ---------------------------------------------------------------------
-        if constexpr (EPI == EPI_RESID_LN) {
+        if constexpr (row_ln(EPI)) {
             // The accumulators already hold x + bias + A W^T: write x back (16 bytes per lane), then LayerNorm
             // of the updated rows: a tile spans whole rows (BN == N), a row's 4 x NT x 4 values sit in the 4
             // waves of one wm group, so the statistics are an in-lane sum, two shuffles and one small LDS
             // exchange; the normalised rows leave as bf16 through the same wide-store path as below.
-            static_assert(EPI != EPI_RESID_LN || WN == 4, "row statistics assume four waves per row");
+            static_assert(!row_ln(EPI) || WN == 4, "row statistics assume four waves per row");
+            // row of the output buffers (EPI_PATCH_LN skips one CLS row per image)
+            auto out_row = [&](int m) { return EPI == EPI_PATCH_LN ? (size_t)(m + m / g.group + 1) : (size_t)m; };
             epi_mark = 0;
             float s1[MT], s2[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + wm * TM + mt * 16 + fr;
+                const size_t mo = out_row(m);
                 s1[mt] = 0.f; s2[mt] = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = wn * TN + nt * 16 + fq * 4;
                     const f32x4 v = acc[nt][mt];
-                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + mo * g.ldx + n) = v;
                     // (explicit fma placement: layernorm_rowtile_kernel in vit_ops.hip repeats these sums
                     // in the same order so that both routes give the same bits)
                     s1[mt] += (v.x + v.y) + (v.z + v.w);
@@ -345,7 +361,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         const int row = idx / OCH, ch = idx % OCH;
                         const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                         const int m = m0 + wm * TM + pass * RP + row;
-                        if (m < g.M) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * TN + ch * 8) = d;
+                        if (m < g.M) *reinterpret_cast<uint4*>(g.ln + out_row(m) * g.ld_ln + wn * TN + ch * 8) = d;
                     }
                     asm volatile("" ::: "memory");
                 }
@@ -432,9 +448,9 @@ int launch_inst(const Gemm8Args& g, hipStream_t s) {
     const int grid = ntiles < resident ? ntiles : resident;
     constexpr int ring = S * (BM + BN) * BK * 2;
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
-    constexpr int extra = EPI == EPI_RESID_LN ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
+    constexpr int extra = row_ln(EPI) ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
     static_assert(ring + extra <= 163840, "LDS budget");
-    const int lds = ring + (EPI == EPI_RESID_LN ? extra : g.N * 4);
+    const int lds = ring + (row_ln(EPI) ? extra : g.N * 4);
     auto kern = gemm8_kernel<EPI, BM, BN, WM, WN, BK, S>;
     static bool attr_done = false;  // per instantiation
     if (!attr_done) {
@@ -497,6 +513,7 @@ int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const flo
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
     g.bias = bias; g.out = out; g.ldo = ldo; g.M = M; g.N = N; g.K = K; g.ntn = 0;
     g.x = nullptr; g.ldx = 0; g.gamma = nullptr; g.beta = nullptr; g.ln = nullptr; g.ld_ln = 0; g.eps = 0.f;
+    g.pos = nullptr; g.group = 1;
     switch (epilogue) {
         case EQUSS_EPI_BF16: return launch<EQUSS_EPI_BF16>(g, s);
         case EQUSS_EPI_GELU_BF16: return launch<EQUSS_EPI_GELU_BF16>(g, s);
@@ -519,8 +536,23 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
     g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
     g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
+    g.pos = nullptr; g.group = 1;
     if (g_stages == 5) return launch_inst<EPI_RESID_LN, 128, 384, 1, 4, 32, 2>(g, s);
     return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);
+}
+
+// Patch embedding as token rows (vision_transformer.py:128-133,:205-209) with the first LayerNorm:
+//   x[b, 1 + t] = pos[1 + t] + bias + cols[b * n + t] W^T ,  ln[b, 1 + t] = LayerNorm(x[b, 1 + t])   (ln may be null)
+// for the M = B * n patch rows; x and ln are (B * (n + 1), 384) token-major, the CLS rows are not touched.
+int gemm8_patch_ln(const void* cols, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* pos, float* x,
+                   const float* gamma, const float* beta, void* ln, int M, int N, int K, int n, float eps, hipStream_t s) {
+    Gemm8Args g;
+    g.A = reinterpret_cast<const u16*>(cols); g.lda = lda;
+    g.W = reinterpret_cast<const u16*>(W); g.ldw = ldw;
+    g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1;
+    g.x = x; g.ldx = N; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = N; g.eps = eps;
+    g.pos = pos; g.group = n;
+    return launch_inst<EPI_PATCH_LN, 128, 384, 2, 4, 64, 2>(g, s);
 }
 
 }  // namespace equss

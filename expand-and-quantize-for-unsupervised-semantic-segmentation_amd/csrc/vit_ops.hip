@@ -7,6 +7,8 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
               int M, int N, int K, int epilogue, hipStream_t s);
 int attention_bf16(const void* qkv, void* out, int B, int N, int H, float scale, hipStream_t s);
 bool gemm8_resid_ln_supports(int N, int K);
+int gemm8_patch_ln(const void* cols, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* pos, float* x,
+                   const float* gamma, const float* beta, void* ln, int M, int N, int K, int n, float eps, hipStream_t s);
 bool mlp_fused_supports(int C, int hidden);
 int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, const float* gamma2, const float* beta2,
                 void* ln_mid, int64_t ld_mid, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
@@ -118,6 +120,20 @@ __global__ __launch_bounds__(256) void assemble_tokens_kernel(const float* __res
     else v = *reinterpret_cast<const f32x4*>(patch + ((size_t)b * n + t - 1) * C + col);
     v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
     *reinterpret_cast<f32x4*>(x + (size_t)row * C + col) = v;
+}
+
+// x[b, 0] = cls + pos[0]: the CLS rows next to the patch rows that the patch GEMM's epilogue writes
+__global__ __launch_bounds__(256) void cls_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos,
+                                                       float* __restrict__ x, int n, int C, long items) {
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= items) return;
+    const int c4 = C / 4;
+    const long b = gid / c4;
+    const int col = (int)(gid % c4) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(cls + col);
+    const f32x4 p = *reinterpret_cast<const f32x4*>(pos + col);
+    v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+    *reinterpret_cast<f32x4*>(x + (size_t)b * (n + 1) * C + col) = v;
 }
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
@@ -303,8 +319,10 @@ int block_balanced(const void* att, const void* wp, const float* bp, const float
     return equss::check_launch("layernorm_rowtile_kernel");
 }
 
+// ln_g / ln_b / ln: optional LayerNorm of the assembled tokens (block 0's norm1), bf16, same row layout as x.
 int patch_tokens(const float* img, const void* w_patch, const float* b_patch, const float* cls, const float* pos,
-                 float* x, void* ws, int B, int H, int W, int P, int C, hipStream_t s) {
+                 float* x, void* ws, int B, int H, int W, int P, int C, hipStream_t s, const float* ln_g = nullptr,
+                 const float* ln_b = nullptr, void* ln = nullptr, bool* ln_done = nullptr) {
     PatchWs w = carve_patch(ws, B, H, W, P, C);
     const int n = (H / P) * (W / P);
     const long items = (long)B * n * 3 * P * (P / 8);
@@ -312,6 +330,19 @@ int patch_tokens(const float* img, const void* w_patch, const float* b_patch, co
                        P, items);
     int rc = equss::check_launch("patch_gather_kernel");
     if (rc) return rc;
+    if (ln_done) *ln_done = false;
+    if (equss::gemm8_resid_ln_supports(C, 3 * P * P)) {
+        // C == 384: the GEMM's epilogue adds the position embedding, writes the token rows and their LayerNorm
+        rc = equss::gemm8_patch_ln(w.cols, 3 * P * P, w_patch, 3 * P * P, b_patch, pos, x, ln_g, ln_b, ln, B * n, C, 3 * P * P, n,
+                                   1e-6f, s);
+        if (rc) return rc;
+        const long items3 = (long)B * (C / 4);
+        hipLaunchKernelGGL(cls_rows_kernel, dim3((unsigned)((items3 + 255) / 256)), dim3(256), 0, s, cls, pos, x, n, C, items3);
+        rc = equss::check_launch("cls_rows_kernel");
+        if (rc || !ln) return rc;
+        if (ln_done) *ln_done = true;
+        return layernorm(x, (int64_t)(n + 1) * C, ln_g, ln_b, ln, (int64_t)(n + 1) * C, nullptr, B, C, 0, 1e-6f, s);
+    }
     rc = equss::gemm_bf16(w.cols, 3 * P * P, w_patch, 3 * P * P, b_patch, w.tmp, C, B * n, C, 3 * P * P, EQUSS_EPI_F32, s);
     if (rc) return rc;
     const long items2 = (long)B * (n + 1) * (C / 4);
@@ -388,9 +419,12 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     VitWs w = carve_vit(workspace, C, B, H, W, P);
     const int n = (H / P) * (W / P), N = n + 1, rows = B * N;
+    bool ln0_done = false;   // block 0's norm1 came out of the patch embedding
     {
         equss::ProfScope ps(EQUSS_K_PATCH, s);
-        rc = patch_tokens(img, vit->patch_w, vit->patch_b, vit->cls, pos, w.x, w.patch, B, H, W, P, C, s);
+        rc = patch_tokens(img, vit->patch_w, vit->patch_b, vit->cls, pos, w.x, w.patch, B, H, W, P, C, s,
+                          vit->depth > 0 ? vit->blocks[0].ln1_g : nullptr, vit->depth > 0 ? vit->blocks[0].ln1_b : nullptr,
+                          vit->depth > 0 ? w.ln : nullptr, &ln0_done);
     }
     if (rc) return rc;
     const float scale = 0.125f;  // head_dim ** -0.5 with head_dim = 64 (vision_transformer.py:71-72)
@@ -407,7 +441,7 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         // norm run as standalone kernels.
         const bool fuse = equss::gemm8_resid_ln_supports(C, C);
         const bool last = i + 1 == vit->depth;
-        if (!fuse || i == 0) {
+        if (!fuse || (i == 0 && !ln0_done)) {
             EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, k.ln1_g, k.ln1_b, w.ln, C, nullptr, rows, C, 0, 1e-6f, s))
         }
         EQUSS_STEP(EQUSS_K_GEMM_QKV, equss::gemm_bf16(w.ln, C, k.qkv_w, C, k.qkv_b, w.qkv, 3 * C, rows, 3 * C, C, EQUSS_EPI_BF16, s))

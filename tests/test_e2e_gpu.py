@@ -197,7 +197,7 @@ def test_training_head_matches_fp32_autograd(pkg, dev):
     w1, b1, w2a, b2a, w2b, b2b = ps
     ref_code = F.linear(rows, w1.view(d, c), b1) + F.linear(F.relu(F.linear(rows, w2a.view(c, c), b2a)), w2b.view(d, c), b2b)
     ref = torch.autograd.grad((ref_code * g_out).sum(), ps)
-    assert float((code - ref_code).norm() / ref_code.norm()) < 1e-2
+    assert float(((code - ref_code).norm() / ref_code.norm()).detach()) < 1e-2
     errs = {name: float((a - b).norm() / b.norm()) for name, a, b in zip(("w1", "b1", "w2a", "b2a", "w2b", "b2b"), got, ref)}
     print("head gradient rel-L2 errors:", errs)
     for name, a, b in zip(errs, got, ref):
