@@ -7,7 +7,7 @@
 //
 // One persistent workgroup (8 waves, one per CU) owns a 128-row tile and walks the hidden dimension
 // in 12 chunks of 128:
-//     G1:  h = gelu(a[128 x 384] W1_c^T + b1_c)     6 K steps of 64; h (128 x 128 bf16) -> LDS
+//     G1:  h = gelu(a[128 x 384] W1_c^T + b1_c)     4 K steps of 96; h (128 x 128 bf16) -> LDS
 //     G2:  acc2[128 x 384] += h W2[:, c]^T          2 K steps of 64, A operand straight from that LDS tile
 // acc2 starts from x + b2 and ends in the same residual + LayerNorm epilogue as the fc2 kernel it
 // replaces; the fp32 operation order per output element (k ascending, x-initialised accumulator) is
@@ -41,7 +41,8 @@ constexpr int kStage = 384 * BK * 2;              // 48 KiB: the W2 slice of a G
 constexpr int S = 2;                              // ring slots: one stage in flight (three 32-KiB slots with 32-wide G2 steps measured 5 % slower)
 constexpr int kHc = BM * HC * 2;                  // 32 KiB
 constexpr int NCH = HID / HC;                     // 12 chunks
-constexpr int G1S = C / BK, G2S = HC / BK;        // 6 + 2 steps per chunk
+constexpr int G1W = 96;                          // G1 steps are 96 wide: three 32-wide sub-tiles (a 8 KiB + W1 8 KiB each) fill a slot
+constexpr int G1S = C / G1W, G2S = HC / BK;       // 4 + 2 steps per chunk
 constexpr int G1L = 4, G2L = 6;                   // LDS-DMA loads per wave in a G1 / G2 stage
 constexpr int G0S = C / 32;                       // PROJ variant: 12 steps of 32 (attention slice 8 KiB + Wp slice 24 KiB)
 constexpr int kLds = S * kStage + kHc + HID * 4 + 6 * C * 4 + BM * WN * 8;
@@ -100,29 +101,26 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) c_off[ks] = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;
     const int a_row = (wm * 64 + fr) * 128;        // + mt * 2048
-    const int w1_row = 16384 + (wn * 32 + fr) * 128;
     const int w2_row = (wn * 96 + fr) * 128;
 
     // ---- staging: 1-KiB pieces of 8 rows; piece p = wave + 8 i, so a wave's pieces share the swizzle --
     const int st_row = lane >> 3;
     const int st_chunk = ((lane & 7) ^ ((4 * (wave & 1) + (st_row >> 1)) & 7)) * 8;   // element offset in the row
-    const int w1_off = (wave * 8 + st_row) * C + st_chunk;          // + 64 * C for the second piece
     const int w2_off = (wave * 8 + st_row) * HID + st_chunk;        // + 64 * HID per further piece
     // G0 slices are 32 wide: rows of 64 B, 16-B chunks swizzled by (row >> 2) & 3, pieces of 16 rows
     const int g0_chunk = ((lane & 3) ^ ((lane >> 4) & 3)) * 8;
     const int g0_row = wave * 16 + (lane >> 2);                     // + 128 per further piece
     const int g0_off = (fq ^ ((fr >> 2) & 3)) * 16;                 // fragment read: chunk fq of row fr
-    const u16* a_src[2];
+    const u16* a_src;   // this lane's 16 bytes of the wave's 16-row piece of the a slice (32-wide sub-tile format)
     const u16* a0_src = nullptr;
     int i_tile = slot, i_p = 0, i_c = 0, i_j = 0, i_buf = 0, issued = 0;
     bool hold_ok = false;   // PROJ: the tile's LayerNorm2 rows are in memory, the first G1 stage may be requested
     auto set_a = [&](int logical) {
         const int m0 = logical * BM;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int am = m0 + (wave + 8 * i) * 8 + st_row;
+        {
+            int am = m0 + g0_row;
             if (am > g.M - 1) am = g.M - 1;   // tail rows re-read the last row; outputs are masked
-            a_src[i] = g.A + (size_t)am * g.lda + st_chunk;
+            a_src = g.A + (size_t)am * g.lda + g0_chunk;
         }
         if (PROJ) {
             int am = m0 + g0_row;
@@ -148,10 +146,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             hold_ok = false;
         }
         if (i_j < G1S) {
+            const u16* w1 = g.W1 + (size_t)(i_c * HC + g0_row) * C + g0_chunk + i_j * G1W;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                glds16(a_src[i] + i_j * BK, base + (wave + 8 * i) * 1024);
-                glds16(g.W1 + (size_t)(i_c * HC + 64 * i) * C + w1_off + i_j * BK, base + 16384 + (wave + 8 * i) * 1024);
+            for (int sub = 0; sub < 3; ++sub) {
+                glds16(a_src + i_j * G1W + sub * 32, base + sub * 8192 + wave * 1024);
+                glds16(w1 + sub * 32, base + 24576 + sub * 8192 + wave * 1024);
             }
         } else {
             const u16* w2 = g.W2 + w2_off + i_c * HC + (i_j - G1S) * BK;
@@ -315,12 +314,14 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             for (int kt = 0; kt < G1S; ++kt) {
                 const char* base = sync_step(kt + 1 < G1S);
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
+                for (int sub = 0; sub < 3; ++sub) {
                     bf16x8 af[4], wf[2];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_row + i * 2048 + c_off[ks]);
+                    for (int i = 0; i < 4; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8*>(base + sub * 8192 + (wm * 64 + i * 16 + fr) * 64 + g0_off);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w1_row + i * 2048 + c_off[ks]);
+                    for (int i = 0; i < 2; ++i)
+                        wf[i] = *reinterpret_cast<const bf16x8*>(base + 24576 + sub * 8192 + (wn * 32 + i * 16 + fr) * 64 + g0_off);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
