@@ -72,6 +72,7 @@ flat = {"attention": summary.get("attention", {}).get("hbm_bytes_per_launch"),
         "mlp_fused": summary.get("mlp_fused", {}).get("hbm_bytes_per_launch"),
         "block_tail": summary.get("block_tail", {}).get("hbm_bytes_per_launch"),
         "gemm_qkv": summary.get("gemm_bf16out", {}).get("hbm_bytes_per_launch")}
+flat = {k: v for k, v in flat.items() if v is not None}
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(flat, f, indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1))
