@@ -5,7 +5,7 @@
  * Python: its "operator interface" for this path is the forward() of a handful of nn.Modules that
  * call stock ATen ops.  Each entry point below replaces the op sequence of one of those forward()s
  * and cites it.  The Python modules that mirror the reference classes bind these symbols with
- * ctypes; nothing here depends on PyTorch.
+ * ctypes (native.py of the package); nothing here depends on PyTorch.
  *
  * Conventions
  *  - Every pointer is a DEVICE pointer on the current HIP device unless noted; the caller owns all
