@@ -47,16 +47,23 @@ def algorithmic_work(cfg, batch, height, width):
     n = (height // p) * (width // p)
     tokens = n + 1
     rows = batch * tokens
+    # ViT-S from 384 row tiles up: one fused launch per block covers the whole rounds of 128-row tiles on
+    # the 256 CUs (proj + MLP), the trailing rows go through one small launch per GEMM (vit_ops.hip)
+    tiles = (rows + 127) // 128
+    fused = c == 384 and tiles >= 384
+    split = fused and tiles // 256 >= 1 and 0 < tiles % 256 <= 128
+    rows_fused = (tiles // 256) * 256 * 128 if split else (rows if fused else 0)
+    rows_gemm = rows - rows_fused          # rows the per-GEMM launches of proj / fc1 / fc2 see
     w = {
         "patch": {"flops": 2.0 * batch * n * (3 * p * p) * c},
         "layernorm": {"bytes": rows * c * (4 + 2)},
         "gemm_qkv": {"flops": 2.0 * rows * c * 3 * c},
         "attention": {"flops": 4.0 * batch * tokens * tokens * c},
-        "gemm_proj": {"flops": 2.0 * rows * c * c},
-        "gemm_fc1": {"flops": 2.0 * rows * c * 4 * c},
-        "gemm_fc2": {"flops": 2.0 * rows * 4 * c * c},
+        "gemm_proj": {"flops": 2.0 * rows_gemm * c * c},
+        "gemm_fc1": {"flops": 2.0 * rows_gemm * c * 4 * c},
+        "gemm_fc2": {"flops": 2.0 * rows_gemm * 4 * c * c},
         "mlp_fused": {"flops": 4.0 * rows * 4 * c * c},     # fc1 + fc2 in one launch (ViT-S)
-        "block_tail": {"flops": 2.0 * rows * c * c + 4.0 * rows * 4 * c * c},   # proj + fc1 + fc2 in one launch (ViT-S)
+        "block_tail": {"flops": 2.0 * rows_fused * c * c + 4.0 * rows_fused * 4 * c * c},   # proj + fc1 + fc2, one launch
         "head_gemm1": {"flops": 2.0 * batch * n * c * c},
         "head_gemm2": {"flops": 2.0 * batch * n * 2 * c * d_out},
         "pq_prep": {"bytes": 2 * num_pq * k * (d_out // num_pq) * 4},

@@ -299,19 +299,30 @@ int block_balanced(const void* att, const void* wp, const float* bp, const float
     const int tiles = (M + 127) / 128, rounds = tiles / 256, rem = tiles % 256;
     const bool split = rounds >= 1 && rem != 0 && rem <= g_mlp_tail_max && hid;
     const int m_main = split ? rounds * 256 * 128 : M, m_tail = M - m_main;
-    int rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s);
+    int rc;
+    {
+        equss::ProfScope ps(EQUSS_K_BLOCK_TAIL, s);   // the fused launch alone; the trailing rows count under the GEMM classes
+        rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s);
+    }
     if (rc || m_tail == 0) return rc;
     const u16* att_tail = reinterpret_cast<const u16*>(att) + (size_t)m_main * C;
     u16* mid_tail = reinterpret_cast<u16*>(ln_mid) + (size_t)m_main * C;
     float* x_tail = x + (size_t)m_main * C;
-    rc = equss::gemm_bf16(att_tail, C, wp, C, bp, x_tail, C, m_tail, C, C, EQUSS_EPI_RESID_F32, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, C, gamma2, beta2, mid_tail, C,
-                       m_tail, eps);
-    rc = equss::check_launch("layernorm_rowtile_kernel");
-    if (rc) return rc;
-    rc = equss::gemm_bf16(mid_tail, C, w1, C, b1, hid, H, m_tail, H, C, EQUSS_EPI_GELU_BF16, s);
-    if (rc) return rc;
+    {
+        equss::ProfScope ps(EQUSS_K_GEMM_PROJ, s);
+        rc = equss::gemm_bf16(att_tail, C, wp, C, bp, x_tail, C, m_tail, C, C, EQUSS_EPI_RESID_F32, s);
+        if (rc) return rc;
+        hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, C, gamma2, beta2, mid_tail,
+                           C, m_tail, eps);
+        rc = equss::check_launch("layernorm_rowtile_kernel");
+        if (rc) return rc;
+    }
+    {
+        equss::ProfScope ps(EQUSS_K_GEMM_FC1, s);
+        rc = equss::gemm_bf16(mid_tail, C, w1, C, b1, hid, H, m_tail, H, C, EQUSS_EPI_GELU_BF16, s);
+        if (rc) return rc;
+    }
+    equss::ProfScope ps(EQUSS_K_GEMM_FC2, s);
     rc = equss::gemm_bf16(hid, H, w2, H, b2, x_tail, C, m_tail, C, H, EQUSS_EPI_RESID_F32, s);
     if (rc || !ln) return rc;
     hipLaunchKernelGGL(layernorm_rowtile_kernel, dim3((m_tail + 15) / 16), dim3(256), 0, s, x_tail, C, gamma, beta,
@@ -450,7 +461,8 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         const bool big = (rows + 127) / 128 >= g_fuse_min_tiles;
         if (fuse && big && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
-            EQUSS_STEP(EQUSS_K_BLOCK_TAIL, block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s))
+            rc = block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s);
+            if (rc) return rc;
             continue;
         }
         if (fuse) {
