@@ -14,8 +14,8 @@
 //    scores: the row max / row sum are in-lane scans plus one cross-half shuffle.
 //  * The S^T accumulators, exponentiated and packed to bf16, are already the B operand of
 //    O^T = V^T P^T (rows of S^T are the summed index), so P never touches LDS.
-//  * Online softmax in fp32 (exp2 with the scale folded in); O is rescaled only when the running
-//    maximum has grown by more than 8 in the exponent.
+//  * Online softmax in fp32 (exp2 with the scale folded in) without a per-tile maximum: the reference
+//    exponent is introduced or raised only when a tile's exponentials leave a safe range (see the kernel).
 //  * Workgroup ids are remapped so the query blocks of one (image, head) run on one XCD and share
 //    its K/V in that XCD's L2.
 #include "equss_common.h"
