@@ -1,5 +1,7 @@
 // Error plumbing of the C ABI: one message buffer per calling thread, no exceptions.
 #include "equss_common.h"
+#include <mutex>
+#include <vector>
 
 namespace equss {
 
@@ -14,6 +16,29 @@ int fail(int code, const char* fmt, ...) {
     vsnprintf(error_buffer(), 512, fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- dynamic-LDS opt-in, once per (kernel, device) ---------------------------------------------
+namespace {
+struct OptIn { const void* kernel; int device; int bytes; };
+std::mutex g_optin_mutex;
+std::vector<OptIn> g_optin;
+}  // namespace
+
+bool lds_opt_in(const void* kernel, int bytes) {
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lock(g_optin_mutex);
+    for (OptIn& o : g_optin)
+        if (o.kernel == kernel && o.device == device) {
+            if (o.bytes >= bytes) return true;
+            if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+            o.bytes = bytes;
+            return true;
+        }
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return false;
+    g_optin.push_back({kernel, device, bytes});
+    return true;
 }
 
 // ---- profiling pool (host objects only; no device memory) ------------------------------------

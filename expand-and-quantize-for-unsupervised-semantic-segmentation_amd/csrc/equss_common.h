@@ -31,6 +31,10 @@ struct ProfScope {
     ~ProfScope() { if (on) prof_end(s); }
 };
 
+// Raise a kernel's dynamic-LDS limit above 64 KiB.  hipFuncSetAttribute acts on the current device, so
+// the opt-in is remembered per (kernel, device) and issued once for each pair.
+bool lds_opt_in(const void* kernel, int bytes);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -452,13 +452,8 @@ int launch_inst(const Gemm8Args& g, hipStream_t s) {
     static_assert(ring + extra <= 163840, "LDS budget");
     const int lds = ring + (row_ln(EPI) ? extra : g.N * 4);
     auto kern = gemm8_kernel<EPI, BM, BN, WM, WN, BK, S>;
-    static bool attr_done = false;  // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                ring + extra) != hipSuccess)
-            return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: cannot reserve %d bytes of LDS", ring + extra);
-        attr_done = true;
-    }
+    if (!equss::lds_opt_in(reinterpret_cast<const void*>(kern), ring + extra))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: cannot reserve %d bytes of LDS", ring + extra);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, g);
     return equss::check_launch("gemm8_kernel");
 }

@@ -450,13 +450,8 @@ bool mlp_fused_supports(int C_, int hidden) { return C_ == C && hidden == HID; }
 namespace {
 template <bool PROJ>
 int launch_mlp(const MlpArgs& g, hipStream_t s) {
-    static bool attr_done = false;   // per instantiation
-    if (!attr_done) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_kernel<PROJ>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLds) != hipSuccess)
-            return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
-        attr_done = true;
-    }
+    if (!lds_opt_in(reinterpret_cast<const void*>(mlp_kernel<PROJ>), kLds))
+        return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
     const int ntiles = (g.M + BM - 1) / BM;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipLaunchKernelGGL(mlp_kernel<PROJ>, dim3(grid), dim3(kThreads), kLds, s, g);

@@ -636,9 +636,7 @@ template <int D, int NT, int ITEMS>
 int launch_assign_items(const PqArgs& a, const PqPlan& pl, int gx, hipStream_t s) {
     const size_t lds = ((size_t)pl.R * D + pl.R + a.K + 2 * (size_t)pl.WK * pl.R + pl.R) * 4;
     auto kern = pq_assign_kernel<D, NT, ITEMS>;
-    if (lds > 65536 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess)
+    if (lds > 65536 && !equss::lds_opt_in(reinterpret_cast<const void*>(kern), 163840))
         return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve %zu bytes of LDS", lds);
     hipLaunchKernelGGL(kern, dim3(gx, a.num_pq), dim3(kPqThreads), lds, s, a);
     return equss::check_launch("pq_assign_kernel");
@@ -738,7 +736,7 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
         if (gx > kMaxGridX) gx = kMaxGridX;
         const size_t lds = (size_t)K * d * 2 + (K + 16) * 4 + (size_t)waves * kScrWaveLds;
         void (*kern)(const PqArgs) = !small ? pq_screen_kernel<128, 6, 4> : (K <= 128 ? pq_screen_kernel<128, 12, 1> : pq_screen_kernel<128, 12, 2>);
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 163840) != hipSuccess)
+        if (!equss::lds_opt_in(reinterpret_cast<const void*>(kern), 163840))
             return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve LDS for the screened search");
         {
             equss::ProfScope ps(EQUSS_K_PQ_ASSIGN, s);

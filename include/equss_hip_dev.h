@@ -1,0 +1,36 @@
+/*
+ * equss_hip_dev.h - developer knobs of libequss_hip.so.  NOT part of the drop-in ABI.
+ *
+ * Each one switches which kernel instance the entry points of equss_hip.h select, for tests that
+ * compare two instances of the same operation and for tuning experiments.  They set process-wide
+ * variables without any synchronisation: call them only from the thread that issues the launches,
+ * between launches, and restore the default afterwards.  The reference has no counterpart.
+ */
+#ifndef EQUSS_HIP_DEV_H
+#define EQUSS_HIP_DEV_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 0 (default): screened fp16 search where it applies; 1: exhaustive fp32 search for every shape. */
+void equss_dev_pq_mode(int mode);
+/* equss_gemm_bf16 instance: 3 (default) large-tile ring kernel where it applies; 0..2 older 128x128 kernels. */
+void equss_dev_gemm_variant(int variant);
+/* large-tile GEMM ring: bits 0..2 = stages (2 default, 3, 4), bit 3 = prefer the 256x256 tile. */
+void equss_dev_gemm_stages(int stages);
+/* CUs a large-tile GEMM launch may occupy (1..256, default 256). */
+void equss_dev_gemm_cu_share(int cus);
+/* waves per attention workgroup: 0 (default) = 4, 8 = the 8-wave variant. */
+void equss_dev_attn_diag(int diag);
+/* ViT-S blocks: 2 (default) proj + MLP in one kernel, 1 MLP in one kernel, 0 one launch per GEMM. */
+void equss_dev_mlp_fused(int on);
+/* largest number of trailing 128-row tiles that leave the fused kernel for the per-GEMM route. */
+void equss_dev_mlp_tail_max(int tiles);
+/* smallest number of 128-row tiles from which the fused kernels are used (default 384). */
+void equss_dev_fuse_min_tiles(int tiles);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EQUSS_HIP_DEV_H */

@@ -11,15 +11,30 @@ import torch
 from conftest import ROOT
 
 
+def _declared(header_name):
+    header = open(os.path.join(ROOT, "include", header_name)).read()
+    return set(re.findall(r"\b(equss_[a-z0-9_]+)\s*\(", header))
+
+
 def test_library_exports_every_declared_symbol(native):
-    header = open(os.path.join(ROOT, "include", "equss_hip.h")).read()
-    declared = set(re.findall(r"\b(equss_[a-z0-9_]+)\s*\(", header))
+    declared = _declared("equss_hip.h")
     assert len(declared) >= 15
     lib = native.load_library()
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libequss_hip.so does not export {sym}"
     assert declared == set(native.EXPORTED_SYMBOLS)
     assert lib.equss_abi_version() == 1
+
+
+def test_library_exports_nothing_undeclared(native):
+    """Every equss_* symbol in the dynamic table is declared in include/equss_hip.h (the drop-in ABI) or in
+    include/equss_hip_dev.h (developer knobs): nothing that changes behaviour hides outside the headers."""
+    import subprocess
+    dev = _declared("equss_hip_dev.h")
+    assert dev == set(native.DEV_SYMBOLS)
+    out = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], stdout=subprocess.PIPE, text=True, check=True).stdout
+    exported = {line.split()[-1] for line in out.splitlines() if line.split() and line.split()[-1].startswith("equss_")}
+    assert exported == _declared("equss_hip.h") | dev, exported ^ (_declared("equss_hip.h") | dev)
 
 
 def test_workspace_queries_need_no_gpu(native):
