@@ -19,6 +19,7 @@
 //    and writes zq / idx coalesced; per-workgroup loss partials are summed in a fixed order by a
 //    second tiny kernel, so the loss is bitwise reproducible run to run.
 #include "equss_common.h"
+#include <mutex>
 
 namespace {
 
@@ -697,10 +698,44 @@ extern "C" size_t equss_pq_workspace_bytes(int rows, int num_pq, int K, int d) {
     return carve(nullptr, num_pq, K, d).bytes;
 }
 
-extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
-                               float* zq, int64_t ld_zq, float* loss_sum, void* workspace,
-                               size_t workspace_bytes, int rows, int num_pq, int K, int d, int normalize,
-                               int gather_normalized, void* stream) {
+namespace {
+
+// Scratch of equss_pq_assign_static: normalised codebooks, their squared norms and the per-workgroup
+// loss partials of one call, i.e. what equss_pq_assign takes as its workspace argument.  One copy per
+// GPU, held until the process ends.  Host code never uses this name as an address: the device address
+// is looked up once per device with hipGetSymbolAddress (static_scratch below).
+constexpr size_t kStaticScratchBytes = 5u << 20;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
+
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mutex;
+void* g_scratch_ptr[kMaxDevices] = {nullptr};
+
+// Device address of `scratch` on the current device (looked up on the first call per device).
+int static_scratch(void** out) {
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess) { equss::fail(0, "pq_assign_static: hipGetDevice: %s", hipGetErrorString(e)); return -(int)e; }
+    if (device < 0 || device >= kMaxDevices)
+        return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign_static: device ordinal %d is outside [0, %d)", device, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !ptr) {
+            equss::fail(0, "pq_assign_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return e != hipSuccess ? -(int)e : -(int)hipErrorInvalidSymbol;
+        }
+        g_scratch_ptr[device] = ptr;
+    }
+    *out = g_scratch_ptr[device];
+    return EQUSS_OK;
+}
+
+int pq_assign_impl(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
+                   float* zq, int64_t ld_zq, float* loss_sum, void* workspace,
+                   size_t workspace_bytes, int rows, int num_pq, int K, int d, int normalize,
+                   int gather_normalized, void* stream) {
     PqPlan pl;
     int rc = check_common(code, ld_code, codebooks, workspace, workspace_bytes, rows, num_pq, K, d, normalize, &pl);
     if (rc) return rc;
@@ -768,6 +803,39 @@ extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* 
         rc = equss::check_launch("pq_loss_reduce");
     }
     return rc;
+}
+
+}  // namespace
+
+extern "C" int equss_pq_assign(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
+                               float* zq, int64_t ld_zq, float* loss_sum, void* workspace,
+                               size_t workspace_bytes, int rows, int num_pq, int K, int d, int normalize,
+                               int gather_normalized, void* stream) {
+    return pq_assign_impl(code, ld_code, codebooks, idx, zq, ld_zq, loss_sum, workspace, workspace_bytes, rows, num_pq,
+                          K, d, normalize, gather_normalized, stream);
+}
+
+extern "C" size_t equss_pq_static_scratch_bytes(void) { return kStaticScratchBytes; }
+
+extern "C" int equss_pq_assign_static(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
+                                      float* zq, int64_t ld_zq, float* loss_sum, int rows, int num_pq, int K, int d,
+                                      int normalize, int gather_normalized, void* stream) {
+    if (rows <= 0 || num_pq <= 0 || K <= 0 || d <= 0)
+        return equss::fail(EQUSS_E_SHAPE, "pq: rows=%d num_pq=%d K=%d d=%d must be positive", rows, num_pq, K, d);
+    const size_t need = equss_pq_workspace_bytes(rows, num_pq, K, d);
+    if (need > kStaticScratchBytes)
+        return equss::fail(EQUSS_E_WORKSPACE,
+                           "pq_assign_static: num_pq=%d K=%d d=%d needs %zu bytes of scratch, the built-in buffer holds "
+                           "%zu (use equss_pq_assign with a caller-owned workspace)", num_pq, K, d, need,
+                           kStaticScratchBytes);
+    void* ws = nullptr;
+    const int rc = static_scratch(&ws);
+    if (rc) return rc;
+    // Every word of the scratch that a call reads is written earlier in the same call (prepared codebooks
+    // by pq_prep_codebook, loss partials by every workgroup of the grid that pq_loss_reduce walks), so
+    // nothing has to be cleared between calls.
+    return pq_assign_impl(code, ld_code, codebooks, idx, zq, ld_zq, loss_sum, ws, kStaticScratchBytes, rows, num_pq, K, d,
+                          normalize, gather_normalized, stream);
 }
 
 extern "C" int equss_pq_prob(const float* code, int64_t ld_code, const float* codebooks, float* prob,

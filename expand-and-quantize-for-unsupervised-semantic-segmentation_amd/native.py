@@ -23,6 +23,7 @@ DEV_SYMBOLS = [   # include/equss_hip_dev.h: developer knobs, not part of the dr
 EXPORTED_SYMBOLS = [
     "equss_abi_version", "equss_last_error", "equss_profile_enable", "equss_profile_read",
     "equss_pq_workspace_bytes", "equss_pq_assign", "equss_pq_prob",
+    "equss_pq_static_scratch_bytes", "equss_pq_assign_static",
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_block_tail_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
@@ -67,6 +68,11 @@ def _declare(lib):
     lib.equss_pq_assign.restype = c_int
     lib.equss_pq_assign.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz,
                                     c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_pq_static_scratch_bytes.restype = c_sz
+    lib.equss_pq_static_scratch_bytes.argtypes = []
+    lib.equss_pq_assign_static.restype = c_int
+    lib.equss_pq_assign_static.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_vp,
+                                           c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
     lib.equss_pq_prob.restype = c_int
     lib.equss_pq_prob.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_sz, c_int, c_int, c_int, c_int, c_int, c_f, c_vp]
     lib.equss_layernorm_bf16.restype = c_int

@@ -111,6 +111,20 @@ int equss_pq_assign(const float* code, int64_t ld_code, const float* codebooks, 
                     int rows, int num_pq, int K, int d, int normalize, int gather_normalized,
                     void* stream);
 
+/* equss_pq_assign for callers that cannot allocate or own device memory beyond inputs and outputs
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * in the reference.  Same arguments, results and bits as equss_pq_assign minus the workspace: the
+ * prepared codebooks and loss partials live in a buffer of equss_pq_static_scratch_bytes() (5 MiB) that
+ * is part of the loaded library on every GPU.  Shapes whose equss_pq_workspace_bytes() exceeds it are
+ * rejected with EQUSS_E_WORKSPACE (both shipped configurations fit: 8 x 256 x 128 needs 1.1 MiB,
+ * 16 x 512 x 128 needs 4.1 MiB).  The call allocates and frees nothing.  All calls on one GPU share that
+ * buffer: calls that may overlap on one GPU (different streams, different host threads) race and must be
+ * serialised by the caller. */
+size_t equss_pq_static_scratch_bytes(void);
+int equss_pq_assign_static(const float* code, int64_t ld_code, const float* codebooks, int64_t* idx,
+                           float* zq, int64_t ld_zq, float* loss_sum, int rows, int num_pq, int K, int d,
+                           int normalize, int gather_normalized, void* stream);
+
 /* softmax(-dist / tau) over the K codewords of every sub-space: the `distance_prob` tensor of
  * model/dino_pqgo.py:655,:699,:774 (and quantizer.py:151,:468 with tau = 1).
  *   prob (rows, num_pq*K) fp32 out. */
