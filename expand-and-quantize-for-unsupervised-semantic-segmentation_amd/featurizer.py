@@ -114,6 +114,14 @@ class VisionTransformer(nn.Module):
             self._pos_cache["pos"] = hit
         return hit[1]
 
+    def invalidate_caches(self) -> None:
+        """Forget the device weight set and the resized position embedding (rebuilt on the next forward).
+        Only needed after parameters were written through ``.data``, which leaves their version counters
+        alone; ordinary in-place writes, load_state_dict and .to() are noticed without it."""
+        self._handle = None
+        self._handle_key = None
+        self._pos_cache = {}
+
     # -- device weight set ------------------------------------------------------------------------
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())

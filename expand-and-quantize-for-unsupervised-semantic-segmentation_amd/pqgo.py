@@ -96,6 +96,9 @@ class STEGOLoss(nn.Module):
     def __init__(self, cfg: dict):
         super().__init__()
         self.cfg = cfg
+        # (coords1, coords2, perms) to use in place of the random draws of the next forward calls
+        # (loss.py:709-710,:725): lets a test replay the draws recorded from another implementation
+        self.replay = None
 
     def helper(self, f1, f2, c1, c2, shift):
         with torch.no_grad():
@@ -117,11 +120,18 @@ class STEGOLoss(nn.Module):
         b = orig_feats.shape[0]
         dev = orig_feats.device
         shape = [b, n, n, 2]
-        coords1 = torch.rand(shape, device=dev) * 2 - 1
-        coords2 = torch.rand(shape, device=dev) * 2 - 1
-        # same random stream as the reference (loss.py:694-731: coords1, coords2, then one permutation per
-        # negative); all point sets of one tensor are then gathered in a single call
-        perms = [_derangement_like(b, dev) for _ in range(self.cfg["neg_samples"])]
+        if self.replay is not None:
+            coords1, coords2, perms = self.replay
+            coords1, coords2 = coords1.to(dev, torch.float32), coords2.to(dev, torch.float32)
+            perms = [p.to(dev, torch.long) for p in perms]
+            if list(coords1.shape) != shape or list(coords2.shape) != shape or len(perms) != self.cfg["neg_samples"]:
+                raise ValueError("STEGOLoss.replay does not match the batch / feature_samples / neg_samples in use")
+        else:
+            coords1 = torch.rand(shape, device=dev) * 2 - 1
+            coords2 = torch.rand(shape, device=dev) * 2 - 1
+            # same random stream as the reference (loss.py:694-731: coords1, coords2, then one permutation
+            # per negative); all point sets of one tensor are then gathered in a single call
+            perms = [_derangement_like(b, dev) for _ in range(self.cfg["neg_samples"])]
         own = torch.arange(b, device=dev)
         coords = torch.stack([coords1] + [coords2] * len(perms))
         which = torch.stack([own] + perms)
@@ -283,7 +293,11 @@ def _quantize_rows(rows, books, normalize, beta, book, training, vq_counts, gath
             # one (num_pq, K) message instead of the reference's num_pq separate K-float all-reduces
             # (dino_pqgo.py:673 inside the python loop at :757)
             counts = all_reduce_tensor(counts, op="sum")
-            if vq_counts is not None:
+            # the running counts are updated BEFORE a restart, which zero-fills them (dino_pqgo.py:675-679,:541)
+            if quantizers is not None:
+                for p, q in enumerate(quantizers):
+                    q.vq_count += counts[p]
+            elif vq_counts is not None:
                 vq_counts += counts
             used = (counts != 0).sum(dim=1).float() / float(k)
             output["codebook-usage"] = float(used.mean())
@@ -348,7 +362,9 @@ class Codebook(nn.Module):
     @torch.no_grad()
     def restart(self) -> None:
         if (self.update_indices is not None) and (self.update_candidates is not None):
-            self.embedding.weight.data[self.update_indices] = self.update_candidates.float()
+            # written through the parameter itself (not .data): that bumps its version counter, which is
+            # what the cached (num_pq, K, d) stack of the eval path is keyed on
+            self.embedding.weight[self.update_indices] = self.update_candidates.float()
             self.vq_count.fill_(0)
             self.update_indices = None
             self.update_candidates = None
@@ -364,7 +380,7 @@ class Codebook(nn.Module):
             from sklearn.cluster import KMeans
             km = KMeans(init="k-means++", n_clusters=self.num_codebook_vectors, random_state=0)
             km.fit(z_flat.detach().cpu().numpy())
-            self.embedding.weight.data.copy_(torch.from_numpy(km.cluster_centers_).float().to(z_flat.device))
+            self.embedding.weight.copy_(torch.from_numpy(km.cluster_centers_).float().to(z_flat.device))
         elif mode == "uni":
             nn.init.xavier_uniform_(self.embedding.weight)
         elif mode == "normal":
@@ -383,7 +399,7 @@ class Codebook(nn.Module):
             self.initialize_from(rows.detach())
         books = self.embedding.weight.unsqueeze(0)
         zq, idx, output = _quantize_rows(rows, books, self.normalize, self.beta, self.book, self.training,
-                                         self.vq_count.unsqueeze(0), use_restart=self.use_restart, quantizers=[self])
+                                         None, use_restart=self.use_restart, quantizers=[self])
         prob = None
         if return_prob:
             prob = native.pq_prob(rows.detach(), books.detach(), self.normalize, self.jsd_ts).reshape(b, h, w, -1)
@@ -424,6 +440,16 @@ class ProductQuantizerWrapper(nn.Module):
             self._books_key = key
         return self._books
 
+    def invalidate_caches(self) -> None:
+        """Drop the cached codebook stack.  Needed only after a weight was written in a way that leaves
+        its version counter alone (``weight.data[...] = ...``, ``weight.data.copy_()``)."""
+        self._books = None
+        self._books_key = None
+
+    def train(self, mode: bool = True):
+        self.invalidate_caches()
+        return super().train(mode)
+
     def forward(self, z: torch.Tensor, z_pos: torch.Tensor = None, it: int = -1, return_prob: bool = True):
         b, dim, h, w = z.shape
         if self.pq_dim not in _PQ_DIMS:
@@ -436,12 +462,8 @@ class ProductQuantizerWrapper(nn.Module):
                 if q.need_initialized != "none":
                     q.initialize_from(rows.detach()[:, i * self.pq_dim:(i + 1) * self.pq_dim])
         books = self.stacked_codebooks()
-        counts = torch.zeros(self.num_pq, q0.num_codebook_vectors, device=z.device) if self.training else None
-        zq, idx, outputs = _quantize_rows(rows, books, q0.normalize, q0.beta, q0.book, self.training, counts,
+        zq, idx, outputs = _quantize_rows(rows, books, q0.normalize, q0.beta, q0.book, self.training, None,
                                           use_restart=q0.use_restart, quantizers=self.quantizers)
-        if self.training:
-            for i, q in enumerate(self.quantizers):
-                q.vq_count += counts[i]
         z_q = _nchw_of(zq, b, h, w)
         z_split = torch.chunk(z, chunks=self.num_pq, dim=1)
         z_quantized = list(torch.chunk(z_q, chunks=self.num_pq, dim=1))
@@ -509,6 +531,21 @@ class DIONPQGO(nn.Module):
         self.eval_streams = 2
         self.eval_stream_min_images = 4   # per stream; smaller ranges leave the chip emptier than one launch does
         self._streams = None
+
+    def invalidate_caches(self) -> None:
+        """Drop every derived weight set (bf16 head and backbone weights, resized position embedding,
+        stacked codebooks) so that the next forward rebuilds them.  The caches notice optimizer steps,
+        load_state_dict and any in-place write made through the parameter itself (those bump its version
+        counter); a write through ``param.data`` does not, and needs this call.  train() / eval() call it."""
+        self._head = None
+        self._head_key = None
+        self.extractor.backbone.invalidate_caches()
+        for blk in self.vq_blocks:
+            blk.invalidate_caches()
+
+    def train(self, mode: bool = True):
+        self.invalidate_caches()
+        return super().train(mode)
 
     # -- expansion head weights for the HIP GEMMs ---------------------------------------------------
     def _head_autograd(self, feat: torch.Tensor) -> torch.Tensor:

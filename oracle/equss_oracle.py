@@ -25,6 +25,7 @@ __all__ = [
     "pqgo_forward", "cluster_lookup", "evaluator_forward", "wrapper_forward",
     "vector_quantizer_forward", "ema_vector_quantizer_eval", "histogram_count", "pq_top2_gap",
     "evaluator_top2_gap", "metrics_confusion", "metrics_compute",
+    "stego_sample", "stego_loss", "train_forward", "TRAINABLE_PREFIXES",
 ]
 
 State = Dict[str, torch.Tensor]
@@ -254,6 +255,100 @@ def pq_top2_gap(weights: List[torch.Tensor], code_rows: torch.Tensor, normalize:
         idxs.append(top2.indices[:, 0])
         gaps.append(top2.values[:, 1] - top2.values[:, 0])
     return torch.stack(idxs), torch.stack(gaps)
+
+
+# --------------------------------------------------------------------------------------------
+# Training step  (model/loss.py:647-739, model/dino_pqgo.py:114-154 with self.training,
+# wrapper/PQGOWrapper.py:52-103)
+# --------------------------------------------------------------------------------------------
+def stego_sample(t: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+    """loss.py:655-656."""
+    return F.grid_sample(t, coords.permute(0, 2, 1, 3), padding_mode="border", align_corners=True)
+
+
+def _stego_helper(cfg, f1, f2, c1, c2, shift):
+    """STEGOLoss.helper, loss.py:677-699."""
+    unit = lambda t: F.normalize(t, dim=1, eps=1e-10)   # noqa: E731  (loss.py:651-652)
+    with torch.no_grad():
+        fd = torch.einsum("nchw,ncij->nhwij", unit(f1), unit(f2))
+        if cfg["pointwise"]:
+            old_mean = fd.mean()
+            fd -= fd.mean([3, 4], keepdim=True)
+            fd = fd - fd.mean() + old_mean
+    cd = torch.einsum("nchw,ncij->nhwij", unit(c1), unit(c2))
+    min_val = 0.0 if cfg["zero_clamp"] else -9999.0
+    if cfg["stabilize"]:
+        return -cd.clamp(min_val, .8) * (fd - shift)
+    return -cd.clamp(min_val) * (fd - shift)
+
+
+def stego_loss(cfg: dict, feats, feats_pos, code, code_pos, coords1, coords2, perms):
+    """STEGOLoss.forward, loss.py:701-739, with its random draws handed in: coords1 / coords2
+    (b, n, n, 2) in [-1, 1) are the two torch.rand draws of :709-710 (already scaled), perms the
+    ``neg_samples`` outputs of super_perm (:659-663, :725) in call order."""
+    f = stego_sample(feats, coords1)
+    c = stego_sample(code, coords1)
+    f_pos = stego_sample(feats_pos, coords2)
+    c_pos = stego_sample(code_pos, coords2)
+    pos_intra = _stego_helper(cfg, f, f, c, c, cfg["pos_intra_shift"])
+    pos_inter = _stego_helper(cfg, f, f_pos, c, c_pos, cfg["pos_inter_shift"])
+    negs = []
+    for perm in perms:
+        f_neg = stego_sample(feats[perm], coords2)
+        c_neg = stego_sample(code[perm], coords2)
+        negs.append(_stego_helper(cfg, f, f_neg, c, c_neg, cfg["neg_inter_shift"]))
+    neg = torch.cat(negs, dim=0)
+    return (cfg["pos_intra_weight"] * pos_intra.mean() + cfg["pos_inter_weight"] * pos_inter.mean() +
+            cfg["neg_inter_weight"] * neg.mean())
+
+
+# the parameters train.py optimises (head, codebooks, probes); the backbone is frozen
+TRAINABLE_PREFIXES = ("model.cluster1.", "model.cluster2.", "model.vq_blocks.", "evaluator.")
+
+
+def train_forward(sd: State, img, img_pos, label, cfg: dict, coords1, coords2, perms, backward: bool = True):
+    """One training forward (+ backward) of PQGOWrapper(DIONPQGO) in fp32 on the CPU:
+    dino_pqgo.py:125-150 with self.training (second ViT pass on img_pos, head on both, PQ, STEGO
+    loss), PQGOWrapper.py:71-101 (loss weights, probes on the detached quantised map).  Restated for
+    need_initialized = "none", use_restart = False and drop_prob = 0 (Dropout2d is then the identity,
+    dino_pqgo.py:126,:133); the STEGO draws are arguments.  Returns (total_loss (1,), output dict,
+    {key: gradient} for every trainable tensor when ``backward``)."""
+    m = cfg["model"]
+    assert m["pretrained"]["drop_prob"] == 0.0 and m["vq"].get("need_initialized", "none") == "none"
+    heads, depth = {"vit_tiny": (3, 12), "vit_small": (6, 12), "vit_base": (12, 12)}[m["pretrained"]["model_type"]]
+    patch = m["pretrained"]["dino_patch_size"]
+    p = {k: (v.detach().clone().requires_grad_(True) if k.startswith(TRAINABLE_PREFIXES) else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        with torch.no_grad():    # frozen backbone, dino_featurizer.py:72-75
+            feat = dino_featurizer(p, img, patch, heads, depth, "model.extractor.backbone.")
+            feat_pos = dino_featurizer(p, img_pos, patch, heads, depth, "model.extractor.backbone.")
+        code = expansion_head(p, feat, "model.")
+        code_pos = expansion_head(p, feat_pos, "model.")
+        vq = m["vq"]
+        quantized, (_zs, _zq, z_index), outputs, _prob = pq_forward(
+            _codebooks(p, "model."), code, vq.get("normalize", "none"), vq["beta"], vq["book"],
+            cfg["loss"]["jsd"].get("temperature", 1.0), True)
+        counts = outputs.pop("_count")
+        outputs["stego-loss"] = stego_loss(cfg["loss"]["stego"], feat, feat_pos, code, code_pos, coords1, coords2, perms)
+        model_loss = torch.zeros(1)
+        if cfg["loss"]["stego_weight"] > 0.0:
+            model_loss = model_loss + outputs["stego-loss"] * cfg["loss"]["stego_weight"]
+        if cfg["loss"]["vq_weight"] > 0.0:
+            model_loss = model_loss + outputs["vq-loss"] * cfg["loss"]["vq_weight"]
+        outputs["loss"] = model_loss
+        otype = cfg["eval"]["output_type"]
+        out = torch.clone(code if otype == "feat" else quantized).detach()
+        linear_loss, _lp, cluster_loss, _cp = evaluator_forward(p, out, label, cfg["num_classes"])
+        outputs["linear-loss"] = linear_loss
+        outputs["cluster-loss"] = cluster_loss
+        total = model_loss + linear_loss + cluster_loss
+        grads = {}
+        if backward:
+            total.backward()
+            grads = {k: v.grad for k, v in p.items() if k.startswith(TRAINABLE_PREFIXES)}
+    outputs["_count"] = torch.stack(counts)
+    outputs["_index"] = torch.stack(z_index, dim=0)
+    return total.detach(), outputs, grads
 
 
 # --------------------------------------------------------------------------------------------

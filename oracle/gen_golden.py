@@ -284,6 +284,7 @@ def main():
 
     probe_and_metric_fixtures(manifest, tmp)
     bcfg_fixture(manifest, tmp)
+    train_fixture(manifest, tmp)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
@@ -293,7 +294,8 @@ def main():
 
 def probe_and_metric_fixtures(manifest, tmp):
     """G9: UnSegEvaluator alone on seeded features (integer and fractional up-sampling factors, and no
-    up-sampling); G10: UnSegMetrics.  `--probes-only` regenerates just these two (`--bcfg-only`: G11)."""
+    up-sampling); G10: UnSegMetrics.  `--probes-only` regenerates just these two (`--bcfg-only`: G11,
+    `--train-only`: G7)."""
     _stub_missing_modules()
     if REF not in sys.path:
         sys.path.insert(0, REF)
@@ -379,6 +381,81 @@ def bcfg_fixture(manifest, tmp):
     manifest["state_dict_keys_bcfg"] = len(state)
 
 
+def train_fixture(manifest, tmp):
+    """G7: one training step of the reference (PQGOWrapper.train(): second ViT pass on img_pos, head on
+    both, PQ with usage counts, STEGO loss, probes; forward + backward) in fp32 on the CPU.  B = 4 at
+    64x64, need_initialized = "none", drop_prob = 0 (Dropout2d the identity).  The STEGO draws
+    (torch.rand x2, super_perm x neg_samples, model/loss.py:709-725) are recorded while the reference
+    runs and frozen with the fixture, so that another implementation can replay them."""
+    DIONPQGO, _RefPQ, _RefCodebook, PQGOWrapper, _refq, _vits = _import_reference()
+    import model.loss as ref_loss
+    cfg = configs.pqgo_config(need_initialized="none", drop_prob=0.0)
+    state = synth.synth_pqgo_state(cfg, seed=1234)
+    wrapper = _ref_wrapper(cfg, state, PQGOWrapper, DIONPQGO, tmp)
+    wrapper.train()
+    img = synth.synth_images(4, 64, 64, seed=71)
+    img_pos = synth.synth_images(4, 64, 64, seed=72)
+    label = synth.synth_labels(4, 64, 64, cfg["num_classes"], seed=71)
+    rec = {"rand": [], "perm": []}
+    real_rand, real_perm, real_sync = torch.rand, ref_loss.super_perm, torch.cuda.synchronize
+
+    def rand(*a, **k):
+        t = real_rand(*a, **k)
+        rec["rand"].append(t.clone())
+        return t
+
+    def perm(size, device):
+        t = real_perm(size, device)
+        rec["perm"].append(t.clone())
+        return t
+
+    torch.manual_seed(7)
+    torch.rand, ref_loss.super_perm, torch.cuda.synchronize = rand, perm, (lambda *a, **k: None)
+    try:
+        with torch.enable_grad():
+            total, out, (lin_p, clu_p), feat_vqs = wrapper(img=img, aug_img=img, label=label, img_pos=img_pos, it=0)
+            total.backward()
+    finally:
+        torch.rand, ref_loss.super_perm, torch.cuda.synchronize = real_rand, real_perm, real_sync
+    assert len(rec["rand"]) == 2 and len(rec["perm"]) == cfg["loss"]["stego"]["neg_samples"]
+    coords1, coords2 = rec["rand"][0] * 2 - 1, rec["rand"][1] * 2 - 1
+    perms = rec["perm"]
+    grads = {k: p.grad for k, p in wrapper.named_parameters() if p.requires_grad}
+    assert len(grads) == 17 and all(g is not None for g in grads.values())
+    assert sorted(out.keys()) == ["cluster-loss", "codebook-usage", "end_time", "linear-loss", "loss", "stego-loss", "vq-loss"]
+
+    o_total, o_out, o_grads = oracle.train_forward(state, img, img_pos, label, cfg, coords1, coords2, perms)
+    _eq(o_total, total.detach(), "G7 total loss")
+    for k in ("vq-loss", "stego-loss", "linear-loss", "cluster-loss", "loss"):
+        _eq(torch.as_tensor(o_out[k]).detach(), torch.as_tensor(out[k]).detach(), f"G7 {k}")
+    assert o_out["codebook-usage"] == out["codebook-usage"]
+    worst = 0.0
+    for k, g in grads.items():
+        assert o_grads[k].shape == g.shape, k
+        worst = max(worst, float((o_grads[k] - g).abs().max() / g.abs().max().clamp_min(1e-30)))
+    # same ATen ops in the same order; autograd's accumulation order into a tensor used twice may differ
+    assert worst < 1e-5, worst
+    manifest["train_step_g7"] = {"oracle_losses_bit_identical": True, "oracle_grad_max_rel_dev": worst,
+                                 "batch": 4, "res": 64, "seed_img": 71, "seed_pos": 72, "torch_seed": 7}
+    vq_counts = torch.stack([q.vq_count for q in wrapper.model.vq_blocks[0].quantizers])
+    assert torch.equal(vq_counts, o_out["_count"])
+    g7 = {"coords1": coords1.numpy(), "coords2": coords2.numpy(), "perms": torch.stack(perms).numpy(),
+          "total": total.detach().numpy(), "codebook_usage": np.float32(out["codebook-usage"]),
+          "vq_count": vq_counts.numpy().astype(np.int32),
+          "index": o_out["_index"].numpy().astype(np.int16),
+          "feat_vqs_absmax": np.float32(feat_vqs.abs().max())}
+    for k in ("vq-loss", "stego-loss", "linear-loss", "cluster-loss", "loss"):
+        g7[k.replace("-", "_")] = np.float32(torch.as_tensor(out[k]).detach().reshape(-1)[0])
+    names = sorted(grads)
+    g7["grad_names"] = np.array(names)
+    g7["grad_norms"] = np.array([float(grads[k].norm()) for k in names], dtype=np.float32)
+    # full gradients of the small tensors, a slice of the large ones
+    for k in names:
+        g = grads[k].detach().reshape(grads[k].shape[0], -1)
+        g7["grad:" + k] = g[:32, :64].numpy().copy()
+    manifest["files"]["g7_train_step"] = _save("g7_train_step", **g7)
+
+
 def probes_only():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
@@ -389,10 +466,12 @@ def probes_only():
         probe_and_metric_fixtures(manifest, tmp)
     if "--bcfg-only" in sys.argv:
         bcfg_fixture(manifest, tmp)
+    if "--train-only" in sys.argv:
+        train_fixture(manifest, tmp)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("probe / metric fixtures written to", OUT)
 
 
 if __name__ == "__main__":
-    probes_only() if ("--probes-only" in sys.argv or "--bcfg-only" in sys.argv) else main()
+    probes_only() if any(a in sys.argv for a in ("--probes-only", "--bcfg-only", "--train-only")) else main()

@@ -173,6 +173,31 @@ def test_point_sampling_matches_grid_sample(pkg):
     torch.testing.assert_close(g_got, g_ref, rtol=1e-5, atol=1e-6)
 
 
+def test_stego_loss_replay_matches_oracle(pkg, oracle):
+    """The package's STEGOLoss (one batched four-neighbour gather per tensor) with replayed draws against
+    the oracle's restatement of loss.py:701-739 (grid_sample per point set), value and gradient, on CPU."""
+    torch.manual_seed(3)
+    cfg = pkg.configs.S_CFG["loss"]["stego"]
+    b, c, d, h, w, n = 3, 24, 40, 6, 7, cfg["feature_samples"]
+    feats, feats_pos = torch.randn(b, c, h, w), torch.randn(b, c, h, w)
+    code = torch.randn(b, d, h, w, requires_grad=True)
+    code_pos = torch.randn(b, d, h, w, requires_grad=True)
+    coords1, coords2 = torch.rand(b, n, n, 2) * 2 - 1, torch.rand(b, n, n, 2) * 2 - 1
+    perms = [pkg.pqgo._derangement_like(b, torch.device("cpu")) for _ in range(cfg["neg_samples"])]
+    want = oracle.stego_loss(cfg, feats, feats_pos, code, code_pos, coords1, coords2, perms)
+    g_want = torch.autograd.grad(want, (code, code_pos))
+    loss_mod = pkg.pqgo.STEGOLoss(cfg)
+    loss_mod.replay = (coords1, coords2, perms)
+    got = loss_mod(feats, feats_pos, code, code_pos)
+    g_got = torch.autograd.grad(got, (code, code_pos))
+    assert abs(float(got) - float(want)) < 1e-6 + 1e-5 * abs(float(want))
+    for a, e in zip(g_got, g_want):
+        assert float((a - e).abs().max()) < 1e-6 + 1e-4 * float(e.abs().max())
+    loss_mod.replay = (coords1[:2], coords2[:2], perms)
+    with pytest.raises(ValueError):
+        loss_mod(feats, feats_pos, code, code_pos)
+
+
 def test_code_index_dump_round_trip(pkg, tmp_path):
     """The index dump (train.py:283-329 sketch): nearest-upsampled indices next to labels, appended
     batch by batch, readable with numpy.load; against F.interpolate(mode="nearest")."""
