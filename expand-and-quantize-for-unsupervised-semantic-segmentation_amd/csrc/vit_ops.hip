@@ -63,14 +63,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float rstd = 1.0f / sqrtf(group_sum<64>(q) * (1.0f / C) + eps);
     const float2* g2 = reinterpret_cast<const float2*>(gamma);
     const float2* b2 = reinterpret_cast<const float2*>(beta);
-    uint32_t* o = reinterpret_cast<uint32_t*>(out + (size_t)orow * ld_out);
+    uint32_t* o = out ? reinterpret_cast<uint32_t*>(out + (size_t)orow * ld_out) : nullptr;
     float2* of = out_f32 ? reinterpret_cast<float2*>(out_f32 + (size_t)orow * C) : nullptr;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
         const float2 g = g2[i * 64 + lane], bb = b2[i * 64 + lane];
         const float y0 = v[i].x * rstd * g.x + bb.x;
         const float y1 = v[i].y * rstd * g.y + bb.y;
-        o[i * 64 + lane] = equss::pack_bf16(y0, y1);
+        if (o) o[i * 64 + lane] = equss::pack_bf16(y0, y1);
         if (of) of[i * 64 + lane] = make_float2(y0, y1);
     }
 }
@@ -413,21 +413,15 @@ extern "C" size_t equss_vit_workspace_bytes(const EqussVit* vit, int B, int H, i
 // prepare_tokens, then per block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))); final norm on
 // the last block's output with the CLS row dropped (vision_transformer.py:106-114,:227-239;
 // dino_featurizer.py:76-81).  ~8 launches per block, all on `stream`, no host synchronisation.
-extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, void* feat_bf16,
-                                 int64_t ld_feat, float* feat_f32, void* workspace, size_t workspace_bytes, int B,
-                                 int H, int W, void* stream) {
-    if (!vit || !img || !pos || !feat_bf16 || !workspace || !vit->blocks)
-        return equss::fail(EQUSS_E_NULL, "vit_forward: null pointer argument");
+// Optional taps: inter (n_last, B*N, C) fp32 = norm(x) after each of the last n_last blocks with the CLS
+// row kept (what get_intermediate_feat returns, :233-239); x_taps (depth, B*N, C) fp32 = the residual
+// stream after every block.
+namespace {
+int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, void* feat_bf16, int64_t ld_feat,
+                     float* feat_f32, void* workspace, int B, int H, int W, hipStream_t s, float* inter, int n_last,
+                     float* x_taps) {
     const int C = vit->embed_dim, P = vit->patch, heads = vit->heads;
-    int rc = check_image(B, H, W, P, C);
-    if (rc) return rc;
-    if (heads * 64 != C) return equss::fail(EQUSS_E_UNSUPPORTED, "vit_forward: head dim must be 64 (C=%d, heads=%d)", C, heads);
-    if (ld_feat < C || (ld_feat % 8) || ((uintptr_t)feat_bf16 % 16) || ((uintptr_t)workspace % 256))
-        return equss::fail(EQUSS_E_ALIGN, "vit_forward: feat must be 16-byte aligned with ld_feat a multiple of 8");
-    if (workspace_bytes < equss_vit_workspace_bytes(vit, B, H, W))
-        return equss::fail(EQUSS_E_WORKSPACE, "vit_forward: workspace of %zu bytes is smaller than the %zu required",
-                           workspace_bytes, equss_vit_workspace_bytes(vit, B, H, W));
-    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    int rc;
     VitWs w = carve_vit(workspace, C, B, H, W, P);
     const int n = (H / P) * (W / P), N = n + 1, rows = B * N;
     bool ln0_done = false;   // block 0's norm1 came out of the patch embedding
@@ -439,14 +433,14 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
     }
     if (rc) return rc;
     const float scale = 0.125f;  // head_dim ** -0.5 with head_dim = 64 (vision_transformer.py:71-72)
-    for (int i = 0; i < vit->depth; ++i) {
-        const EqussVitBlock& k = vit->blocks[i];
 #define EQUSS_STEP(cls, call)                 \
     {                                         \
         equss::ProfScope ps(cls, s);          \
         rc = (call);                          \
     }                                         \
     if (rc) return rc;
+    auto run_block = [&](int i) -> int {
+        const EqussVitBlock& k = vit->blocks[i];
         // With C == 384 the residual GEMMs also emit the LayerNorm their consumer needs (norm2 of this
         // block after proj, norm1 of the next block after fc2), so only block 0's norm1 and the final
         // norm run as standalone kernels.
@@ -461,9 +455,7 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         const bool big = (rows + 127) / 128 >= g_fuse_min_tiles;
         if (fuse && big && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
-            rc = block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s);
-            if (rc) return rc;
-            continue;
+            return block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s);
         }
         if (fuse) {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, resid_ln_balanced(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
@@ -474,7 +466,7 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         if (fuse && big && g_mlp_fused && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
             EQUSS_STEP(EQUSS_K_MLP_FUSED, mlp_balanced(w.ln, C, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, C, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, C, w.hid, rows, 1e-6f, s))
-            continue;
+            return EQUSS_OK;
         }
         EQUSS_STEP(EQUSS_K_GEMM_FC1, equss::gemm_bf16(w.ln, C, k.fc1_w, C, k.fc1_b, w.hid, 4 * C, rows, 4 * C, C, EQUSS_EPI_GELU_BF16, s))
         if (fuse) {
@@ -483,9 +475,66 @@ extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const fl
         } else {
             EQUSS_STEP(EQUSS_K_GEMM_FC2, equss::gemm_bf16(w.hid, 4 * C, k.fc2_w, 4 * C, k.fc2_b, w.x, C, rows, C, 4 * C, EQUSS_EPI_RESID_F32, s))
         }
+        return EQUSS_OK;
+    };
+    const size_t tap = (size_t)rows * C;
+    for (int i = 0; i < vit->depth; ++i) {
+        rc = run_block(i);
+        if (rc) return rc;
+        if (x_taps) {
+            hipError_t e = hipMemcpyAsync(x_taps + (size_t)i * tap, w.x, tap * sizeof(float), hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) { equss::fail(0, "vit_forward: copy of the residual tap: %s", hipGetErrorString(e)); return -(int)e; }
+        }
+        const int from_end = vit->depth - i;   // the reference keeps norm(x) of block i when depth - i <= n (:235-236)
+        if (inter && from_end <= n_last) {
+            EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, vit->norm_g, vit->norm_b, nullptr, C, inter + (size_t)(n_last - from_end) * tap, rows, C, 0, 1e-6f, s))
+        }
     }
-    EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, vit->norm_g, vit->norm_b, feat_bf16, ld_feat, feat_f32, rows, C, N, 1e-6f, s))
+    if (feat_bf16 || feat_f32) {
+        EQUSS_STEP(EQUSS_K_LAYERNORM, layernorm(w.x, C, vit->norm_g, vit->norm_b, feat_bf16, ld_feat, feat_f32, rows, C, N, 1e-6f, s))
+    }
     return EQUSS_OK;
+}
+
+int check_vit(const EqussVit* vit, const float* img, const float* pos, void* workspace, size_t workspace_bytes, int B,
+              int H, int W, const char* who) {
+    if (!vit || !img || !pos || !workspace || !vit->blocks) return equss::fail(EQUSS_E_NULL, "%s: null pointer argument", who);
+    const int C = vit->embed_dim;
+    int rc = check_image(B, H, W, vit->patch, C);
+    if (rc) return rc;
+    if (vit->heads * 64 != C) return equss::fail(EQUSS_E_UNSUPPORTED, "%s: head dim must be 64 (C=%d, heads=%d)", who, C, vit->heads);
+    if ((uintptr_t)workspace % 256) return equss::fail(EQUSS_E_ALIGN, "%s: workspace must be 256-byte aligned", who);
+    if (workspace_bytes < equss_vit_workspace_bytes(vit, B, H, W))
+        return equss::fail(EQUSS_E_WORKSPACE, "%s: workspace of %zu bytes is smaller than the %zu required", who,
+                           workspace_bytes, equss_vit_workspace_bytes(vit, B, H, W));
+    return EQUSS_OK;
+}
+}  // namespace
+
+extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, void* feat_bf16,
+                                 int64_t ld_feat, float* feat_f32, void* workspace, size_t workspace_bytes, int B,
+                                 int H, int W, void* stream) {
+    if (!feat_bf16) return equss::fail(EQUSS_E_NULL, "vit_forward: null pointer argument");
+    int rc = check_vit(vit, img, pos, workspace, workspace_bytes, B, H, W, "vit_forward");
+    if (rc) return rc;
+    if (ld_feat < vit->embed_dim || (ld_feat % 8) || ((uintptr_t)feat_bf16 % 16) || (feat_f32 && ((uintptr_t)feat_f32 % 8)))
+        return equss::fail(EQUSS_E_ALIGN, "vit_forward: feat must be 16-byte aligned with ld_feat a multiple of 8");
+    return vit_forward_impl(vit, img, pos, feat_bf16, ld_feat, feat_f32, workspace, B, H, W,
+                            reinterpret_cast<hipStream_t>(stream), nullptr, 0, nullptr);
+}
+
+extern "C" int equss_vit_intermediate_feat(const EqussVit* vit, const float* img, const float* pos, float* feats,
+                                           int n_last, float* x_taps, void* workspace, size_t workspace_bytes, int B,
+                                           int H, int W, void* stream) {
+    if (!feats) return equss::fail(EQUSS_E_NULL, "vit_intermediate_feat: null pointer argument");
+    int rc = check_vit(vit, img, pos, workspace, workspace_bytes, B, H, W, "vit_intermediate_feat");
+    if (rc) return rc;
+    if (n_last < 1 || n_last > vit->depth)
+        return equss::fail(EQUSS_E_SHAPE, "vit_intermediate_feat: n_last=%d must lie in [1, depth=%d]", n_last, vit->depth);
+    if (((uintptr_t)feats % 8) || (x_taps && ((uintptr_t)x_taps % 8)))
+        return equss::fail(EQUSS_E_ALIGN, "vit_intermediate_feat: outputs must be 8-byte aligned");
+    return vit_forward_impl(vit, img, pos, nullptr, vit->embed_dim, nullptr, workspace, B, H, W,
+                            reinterpret_cast<hipStream_t>(stream), feats, n_last, x_taps);
 }
 
 extern "C" int equss_gemm_resid_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,

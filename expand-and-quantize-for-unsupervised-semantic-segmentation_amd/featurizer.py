@@ -161,16 +161,27 @@ class VisionTransformer(nn.Module):
         pos = self._pos_for(h, w)  # the reference names dims 2,3 "w, h"; the maths is symmetric in them
         return native.vit_forward(self.device_handle(), img, pos, feat_bf16=feat_bf16, want_f32=want_f32)
 
+    @torch.no_grad()
     def get_intermediate_feat(self, x, n=1):
-        """vision_transformer.py:227-239 for n=1.  Returns ([feat], [], []) where feat holds the
-        patch tokens (B, 1+n, C) with a zero CLS row: the attention maps and qkv the reference also
-        returns are never produced by the fused kernels (its caller drops them)."""
-        if n != 1:
-            raise NotImplementedError("only the last block's features are produced on the HIP path")
-        b = x.shape[0]
-        _, f32 = self.patch_features(x, want_f32=True)
-        f32 = f32.reshape(b, -1, self.embed_dim)
-        return [torch.cat((torch.zeros_like(f32[:, :1]), f32), dim=1)], [], []
+        """vision_transformer.py:227-239: ([norm(x) after each of the last n blocks, (B, 1+n_patches, C)
+        fp32 with the CLS row], [], []).  The attention maps and qkv the reference also returns are never
+        formed by the fused attention kernel (its only caller drops them, dino_featurizer.py:76-80), so
+        those two lists stay empty."""
+        if not 1 <= n <= self.depth:
+            raise ValueError(f"n={n} must lie in [1, {self.depth}]")
+        img = x.detach().to(torch.float32).contiguous()
+        _, _, h, w = img.shape
+        feats = native.vit_intermediate_feat(self.device_handle(), img, self._pos_for(h, w), n_last=n)
+        return [feats[i] for i in range(n)], [], []
+
+    @torch.no_grad()
+    def residual_taps(self, x):
+        """The fp32 residual stream after every block, (depth, B, 1+n_patches, C): for parity checks
+        against per-block reference outputs."""
+        img = x.detach().to(torch.float32).contiguous()
+        _, _, h, w = img.shape
+        _feats, taps = native.vit_intermediate_feat(self.device_handle(), img, self._pos_for(h, w), n_last=1, want_taps=True)
+        return taps
 
     def forward(self, x):
         raise NotImplementedError("the CLS-token classifier output is not part of the EQUSS path")

@@ -26,7 +26,7 @@ EXPORTED_SYMBOLS = [
     "equss_pq_static_scratch_bytes", "equss_pq_assign_static",
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_block_tail_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
-    "equss_vit_workspace_bytes", "equss_vit_forward", "equss_expand_head",
+    "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
     "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
 ]
 
@@ -100,6 +100,9 @@ def _declare(lib):
     lib.equss_vit_forward.restype = c_int
     lib.equss_vit_forward.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz,
                                       c_int, c_int, c_int, c_vp]
+    lib.equss_vit_intermediate_feat.restype = c_int
+    lib.equss_vit_intermediate_feat.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_sz,
+                                                c_int, c_int, c_int, c_vp]
     lib.equss_expand_head.restype = c_int
     lib.equss_expand_head.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]
     lib.equss_probe_workspace_bytes.restype = c_sz
@@ -233,8 +236,12 @@ def pq_prob(code_rows, codebooks, normalize="l2", tau=1.0):
     """softmax(-dist / tau) over the K codewords: (rows, num_pq*K) fp32."""
     lib = load_library()
     _need_cuda(code_rows, codebooks)
+    if code_rows.dtype != torch.float32 or codebooks.dtype != torch.float32:
+        raise ValueError("pq_prob computes in fp32: code and codebooks must be float32")
     num_pq, k, d = codebooks.shape
     rows, width = code_rows.shape
+    if width != num_pq * d:
+        raise ValueError(f"code has {width} channels, codebooks need {num_pq}x{d}")
     if code_rows.stride(1) != 1 or code_rows.stride(0) % 4 != 0 or code_rows.data_ptr() % 16 != 0:
         code_rows = code_rows.contiguous()
     codebooks = codebooks.contiguous()
@@ -389,6 +396,25 @@ def vit_forward(handle, img, pos, feat_bf16=None, ld_feat=None, want_f32=False):
                                _ptr(ws), ws.numel(), b, h, w, _stream(img))
     _check(rc, "equss_vit_forward")
     return (feat_bf16, feat_f32) if want_f32 else feat_bf16
+
+
+def vit_intermediate_feat(handle, img, pos, n_last=1, want_taps=False):
+    """norm(x) after each of the last ``n_last`` blocks, CLS row kept: (n_last, B, 1+n, C) fp32
+    (vision_transformer.py:227-239); with want_taps also the residual stream after every block,
+    (depth, B, 1+n, C) fp32."""
+    lib = load_library()
+    _need_cuda(img, pos)
+    b, _, h, w = img.shape
+    c = handle.embed_dim
+    tokens = (h // handle.patch) * (w // handle.patch) + 1
+    feats = torch.empty((n_last, b, tokens, c), dtype=torch.float32, device=img.device)
+    taps = torch.empty((handle.depth, b, tokens, c), dtype=torch.float32, device=img.device) if want_taps else None
+    nbytes = lib.equss_vit_workspace_bytes(ctypes.byref(handle.struct), b, h, w)
+    ws = _workspace(img.device, nbytes, "vit")
+    rc = lib.equss_vit_intermediate_feat(ctypes.byref(handle.struct), _ptr(img), _ptr(pos), _ptr(feats), int(n_last),
+                                         _ptr(taps), _ptr(ws), ws.numel(), b, h, w, _stream(img))
+    _check(rc, "equss_vit_intermediate_feat")
+    return (feats, taps) if want_taps else feats
 
 
 def expand_head(fh, w2a, b2a, w_cat, b_cat, out_dim, out=None):

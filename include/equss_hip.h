@@ -236,6 +236,17 @@ int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, v
                       int64_t ld_feat, float* feat_f32, void* workspace, size_t workspace_bytes,
                       int B, int H, int W, void* stream);
 
+/* VisionTransformer.get_intermediate_feat (model/dino/vision_transformer.py:227-239): the same forward,
+ * returning what that method returns as `feat`: norm(x) after each of the last n_last blocks, CLS row
+ * kept.  (Its other two results, the attention maps and qkv of those blocks, are never formed by the fused
+ * attention kernel; the reference's only caller drops them, dino_featurizer.py:76-80.)
+ *   feats  (n_last, B*(1+n), C) fp32 out, oldest block first (the order of the reference's list)
+ *   x_taps (depth, B*(1+n), C) fp32 out or NULL: the residual stream after every block
+ *   workspace: equss_vit_workspace_bytes() bytes. */
+int equss_vit_intermediate_feat(const EqussVit* vit, const float* img, const float* pos, float* feats,
+                                int n_last, float* x_taps, void* workspace, size_t workspace_bytes,
+                                int B, int H, int W, void* stream);
+
 /* Expansion head (model/dino_pqgo.py:104-112,:127-128):
  *   code = W1 f + b1 + W2b relu(W2a f + b2a) + b2b, evaluated as two GEMMs:
  *   h = relu(f W2a^T + b2a) written beside f, then code = [f | h] [W1 | W2b]^T + (b1 + b2b).

@@ -26,6 +26,7 @@ __all__ = [
     "vector_quantizer_forward", "ema_vector_quantizer_eval", "histogram_count", "pq_top2_gap",
     "evaluator_top2_gap", "metrics_confusion", "metrics_compute",
     "stego_sample", "stego_loss", "train_forward", "TRAINABLE_PREFIXES",
+    "quantizer_pq_eval", "ema_vector_quantizer_train",
 ]
 
 State = Dict[str, torch.Tensor]
@@ -511,5 +512,59 @@ def ema_vector_quantizer_eval(weight: torch.Tensor, z_flat: torch.Tensor, normal
     commitment_loss = F.mse_loss(z_norm, zq.detach())
     out = {"loss": beta * commitment_loss, "commitment-loss": commitment_loss,
            "codebook-sum": torch.sum(torch.abs(weight))}
+    zq = z_norm + (zq - z_norm).detach()
+    return zq, out, prob, idx
+
+
+def quantizer_pq_eval(weights: List[torch.Tensor], z_flat: torch.Tensor, normalize: str = "l2", beta: float = 0.25,
+                      update_norm: bool = True):
+    """model/quantizer.py's ProductQuantizerWrapper.forward (:587-611) over EMAVectorQuantizers in eval
+    mode on flat (n, D) input: chunk the channels, quantise each group, concatenate, average the dicts."""
+    num_pq = len(weights)
+    qs, probs, outputs = [], [], {}
+    for i, z_i in enumerate(torch.chunk(z_flat, chunks=num_pq, dim=1)):
+        q_i, out_i, prob_i, _idx = ema_vector_quantizer_eval(weights[i], z_i, normalize, beta, update_norm)
+        qs.append(q_i)
+        probs.append(prob_i)
+        for k, v in out_i.items():
+            outputs[k] = v if i == 0 else outputs[k] + v
+    for k in outputs:
+        outputs[k] = outputs[k] / num_pq
+    return torch.cat(qs, dim=1), outputs, torch.cat(probs, dim=-1)
+
+
+def ema_vector_quantizer_train(state: Dict[str, torch.Tensor], z_flat: torch.Tensor, normalize: str = "l2",
+                               beta: float = 0.25, decay: float = 0.99, eps: float = 1e-5, update_norm: bool = True):
+    """EMAVectorQuantizer.forward in TRAINING mode (quantizer.py:383-542 with :480-510) on one process,
+    after any first-call initialisation, use_restart = use_split = False.  ``state`` holds the buffers
+    ``weight``, ``weight_avg``, ``ema_count`` (EmbeddingEMA.vq_count, :221) and ``vq_count`` (the module's
+    own running count, :493) and is UPDATED IN PLACE as the reference updates its buffers (:233-254).
+    Returns (z_q (n, d), output dict, distance_prob (n, K), idx (n,))."""
+    weight = state["weight"]
+    k = weight.shape[0]
+    z_norm, codebook_norm = _normalize_pair(z_flat, weight, normalize)
+    dist = _sq_distance(z_norm, codebook_norm)
+    idx = torch.argmin(dist, dim=1)
+    prob = F.softmax(-dist * 1.0, dim=1)
+    zq = F.embedding(idx, codebook_norm) if update_norm else F.embedding(idx, weight)
+    out = {}
+    with torch.no_grad():
+        one_hot = F.one_hot(idx, k).to(z_flat.dtype)
+        cur = torch.sum(one_hot, dim=0)
+        cur_sum = torch.matmul(one_hot.t(), z_flat)
+        state["vq_count"] += cur
+        out.update(histogram_count(state["vq_count"], prefix="total"))
+        out.update(histogram_count(cur, prefix="current"))
+        state["ema_count"].mul_(decay).add_(cur, alpha=1 - decay)
+        state["weight_avg"].mul_(decay).add_(cur_sum, alpha=1 - decay)
+        n = state["ema_count"].sum()
+        smoothed = (state["ema_count"] + eps) / (n + k * eps) * n
+        new_weight = state["weight_avg"] / smoothed.unsqueeze(1)
+        out["codebook-usage"] = (k - len(torch.nonzero(cur == 0, as_tuple=True)[0])) / k
+    commitment_loss = F.mse_loss(z_norm, zq.detach())
+    state["weight"] = new_weight          # the reference copies into the buffer before reading it at :532
+    out["loss"] = beta * commitment_loss
+    out["commitment-loss"] = commitment_loss
+    out["codebook-sum"] = torch.sum(torch.abs(new_weight))
     zq = z_norm + (zq - z_norm).detach()
     return zq, out, prob, idx

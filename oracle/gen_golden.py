@@ -285,6 +285,7 @@ def main():
     probe_and_metric_fixtures(manifest, tmp)
     bcfg_fixture(manifest, tmp)
     train_fixture(manifest, tmp)
+    quantizer_train_fixture(manifest, tmp)
 
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
@@ -295,7 +296,7 @@ def main():
 def probe_and_metric_fixtures(manifest, tmp):
     """G9: UnSegEvaluator alone on seeded features (integer and fractional up-sampling factors, and no
     up-sampling); G10: UnSegMetrics.  `--probes-only` regenerates just these two (`--bcfg-only`: G11,
-    `--train-only`: G7)."""
+    `--train-only`: G7, `--quantizer-only`: G8b)."""
     _stub_missing_modules()
     if REF not in sys.path:
         sys.path.insert(0, REF)
@@ -456,6 +457,65 @@ def train_fixture(manifest, tmp):
     manifest["files"]["g7_train_step"] = _save("g7_train_step", **g7)
 
 
+def quantizer_train_fixture(manifest, tmp):
+    """G8b: model/quantizer.py's EMAVectorQuantizer in TRAINING mode (two consecutive forwards on flat
+    input, so that the EMA buffers evolve) and its ProductQuantizerWrapper in eval mode, plus the running
+    usage histograms VectorQuantizer reports."""
+    _DIONPQGO, _RefPQ, _RefCodebook, _PQGOWrapper, refq, _vits = _import_reference()
+    rng = np.random.Generator(np.random.PCG64(33))
+    k, d, n = 64, 32, 600
+    w = torch.from_numpy(rng.standard_normal((k, d)).astype(np.float32))
+    # clustered rows so that several codewords stay unused (usage < 1, p-quantiles informative)
+    centres = rng.standard_normal((12, d)).astype(np.float32)
+    zs = [torch.from_numpy((centres[rng.integers(0, 12, size=n)] + 0.3 * rng.standard_normal((n, d))).astype(np.float32))
+          for _ in range(2)]
+    ema = refq.EMAVectorQuantizer(k, d, beta=0.25, normalize="l2", decay=0.9, eps=1e-5).train()
+    ema.codebook.weight.data.copy_(w)
+    ema.codebook.weight_avg.data.copy_(w)
+    st = {"weight": w.clone(), "weight_avg": w.clone(), "ema_count": torch.zeros(k), "vq_count": torch.zeros(k)}
+    g = {"weight": w.numpy(), "z0": zs[0].numpy(), "z1": zs[1].numpy(), "meta": np.array([k, d, n], dtype=np.int64),
+         "decay": np.float32(0.9), "eps": np.float32(1e-5)}
+    for step, z in enumerate(zs):
+        q, o, p = ema(z)
+        oq, oo, op, oidx = oracle.ema_vector_quantizer_train(st, z, "l2", 0.25, 0.9, 1e-5, True)
+        _eq(oq, q, f"G8b step {step} q")
+        _eq(op, p, f"G8b step {step} prob")
+        for key in ("loss", "commitment-loss", "codebook-sum"):
+            _eq(oo[key], o[key], f"G8b step {step} {key}")
+        for key in o:
+            if key.startswith(("total", "current")) or key == "codebook-usage":
+                assert oo[key] == o[key], (key, oo[key], o[key])
+        _eq(st["weight"], ema.codebook.weight, f"G8b step {step} weight")
+        _eq(st["weight_avg"], ema.codebook.weight_avg, f"G8b step {step} weight_avg")
+        _eq(st["ema_count"], ema.codebook.vq_count, f"G8b step {step} ema count")
+        _eq(st["vq_count"], ema.vq_count, f"G8b step {step} vq_count")
+        g.update({f"s{step}_q": q.detach().numpy(), f"s{step}_idx": oidx.numpy().astype(np.int16),
+                  f"s{step}_loss": np.float32(o["loss"]), f"s{step}_usage": np.float32(o["codebook-usage"]),
+                  f"s{step}_codebook_sum": np.float32(o["codebook-sum"]),
+                  f"s{step}_hist": np.array([-1.0 if o[f"{a}-{b}"] is None else o[f"{a}-{b}"]
+                                             for a in ("total", "current") for b in ("p10", "p50", "p90")], dtype=np.float64),
+                  f"s{step}_weight": ema.codebook.weight.numpy().copy(), f"s{step}_weight_avg": ema.codebook.weight_avg.numpy().copy(),
+                  f"s{step}_ema_count": ema.codebook.vq_count.numpy().copy(), f"s{step}_vq_count": ema.vq_count.numpy().copy()})
+    # VectorQuantizer: the histograms it reports (it counts in eval mode too, quantizer.py:157-169)
+    z4 = zs[0][:576].reshape(2, 18, 16, d).permute(0, 3, 1, 2).contiguous()
+    vqm = refq.VectorQuantizer(k, d, beta=0.25, normalize="l2").eval()
+    vqm.codebook.weight.data.copy_(w)
+    for _ in range(2):
+        q, o, p = vqm(z4)
+    g.update({"vq_hist": np.array([-1.0 if o[f"{a}-{b}"] is None else o[f"{a}-{b}"]
+                                   for a in ("total", "current") for b in ("p10", "p50", "p90")], dtype=np.float64),
+              "vq_count": vqm.vq_count.numpy().copy(), "vq_q": q.numpy(), "vq_loss": np.float32(o["loss"])})
+    # the PQ wrapper over EMA quantisers, eval mode
+    g8 = dict(np.load(os.path.join(OUT, "g8_quantizer_py.npz")))
+    books = [torch.from_numpy(b) for b in g8["pq_books"]]
+    zf = _rows(torch.from_numpy(g8["z"])).contiguous()
+    wq, wo, wp = oracle.quantizer_pq_eval(books, zf, "l2", 0.25, True)
+    _eq(wq, torch.from_numpy(g8["pq_q"]), "G8 pq_q via the oracle wrapper")
+    _eq(wp[:8], torch.from_numpy(g8["pq_prob8"]), "G8 pq_prob8 via the oracle wrapper")
+    assert abs(float(wo["loss"]) - float(g8["pq_loss"])) == 0.0
+    manifest["files"]["g8b_quantizer_train"] = _save("g8b_quantizer_train", **g)
+
+
 def probes_only():
     torch.manual_seed(0)
     torch.set_grad_enabled(False)
@@ -468,10 +528,12 @@ def probes_only():
         bcfg_fixture(manifest, tmp)
     if "--train-only" in sys.argv:
         train_fixture(manifest, tmp)
+    if "--quantizer-only" in sys.argv:
+        quantizer_train_fixture(manifest, tmp)
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print("probe / metric fixtures written to", OUT)
 
 
 if __name__ == "__main__":
-    probes_only() if any(a in sys.argv for a in ("--probes-only", "--bcfg-only", "--train-only")) else main()
+    probes_only() if any(a in sys.argv for a in ("--probes-only", "--bcfg-only", "--train-only", "--quantizer-only")) else main()

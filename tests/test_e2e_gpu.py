@@ -42,8 +42,32 @@ def test_vit_features_64px(wrapper, pkg, golden, dev):
     print("G1 feature rel-L2:", err, "max abs:", float(np.abs(f32.cpu().numpy() - want).max()))
     assert err < FEAT_REL_L2
     assert _rel_l2(bf.float().cpu().numpy(), want) < FEAT_REL_L2
+    # get_intermediate_feat (vision_transformer.py:227-239): CLS row included, n > 1 keeps norm(x) per block
     feats, attns, qkvs = bb.get_intermediate_feat(img, n=1)
-    assert feats[0].shape == (2, 65, 384)
+    assert len(feats) == 1 and feats[0].shape == (2, 65, 384) and attns == [] and qkvs == []
+    assert _rel_l2(feats[0].cpu().numpy(), g["feat"]) < FEAT_REL_L2
+    assert _rel_l2(feats[0][:, 0].cpu().numpy(), g["feat"][:, 0]) < FEAT_REL_L2          # the CLS feature itself
+    assert torch.equal(feats[0][:, 1:].reshape(-1, 384), f32)
+    feats3, _, _ = bb.get_intermediate_feat(img, n=3)
+    assert len(feats3) == 3 and torch.equal(feats3[2], feats[0])
+    with pytest.raises(ValueError):
+        bb.get_intermediate_feat(img, n=13)
+
+
+def test_vit_residual_stream_taps_64px(wrapper, pkg, golden, dev):
+    """The fp32 residual stream after blocks 0, 5 and 11 against the reference's (golden taps of G1), and
+    norm(x) of the block before last against LayerNorm of the reference's tap."""
+    g = golden("g1_vit_64")
+    img = pkg.synth.synth_images(2, 64, 64, seed=11).to(dev)
+    bb = wrapper.model.extractor.backbone
+    taps = bb.residual_taps(img)
+    assert taps.shape == (12, 2, 65, 384)
+    errs = {i: _rel_l2(taps[i].cpu().numpy(), g[f"block{i}"]) for i in (0, 5, 11)}
+    print("residual-stream rel-L2 after blocks 0 / 5 / 11:", errs)
+    assert errs[0] < 5e-3 and errs[5] < 1e-2 and errs[11] < FEAT_REL_L2
+    feats2, _, _ = bb.get_intermediate_feat(img, n=2)
+    want = torch.nn.functional.layer_norm(taps[10], (384,), bb.norm.weight, bb.norm.bias, 1e-6)
+    assert float((feats2[0] - want).abs().max()) < 1e-4
 
 
 def test_featurizer_non_square(wrapper, pkg, golden, dev):
@@ -92,7 +116,7 @@ def test_full_forward_scfg_b4_320(wrapper, pkg, oracle, golden, dev):
     hist_l1 = float(np.abs(hist - g["hist"]).sum() / g["hist"].sum())
     print(f"G5 end-to-end code-index agreement with the fp32 reference: {agree:.4f}; "
           f"usage-histogram L1 distance {hist_l1:.4f}; near-tie flips on own code: {flips}")
-    assert agree > 0.80
+    assert agree > 0.985         # measured 0.992
     # losses
     assert abs(float(out["vq-loss"]) - float(g["vq_loss"])) < 2e-2 * float(g["vq_loss"])
     assert abs(float(out["linear-loss"]) - float(g["linear_loss"])) < 3e-2 * abs(float(g["linear_loss"]))
@@ -101,7 +125,37 @@ def test_full_forward_scfg_b4_320(wrapper, pkg, oracle, golden, dev):
     lin_agree = float((lin_p.reshape(-1)[pix].cpu().numpy() == g["linear_preds"]).mean())
     clu_agree = float((clu_p.reshape(-1)[pix].cpu().numpy() == g["cluster_preds"]).mean())
     print(f"probe agreement: linear {lin_agree:.4f} cluster {clu_agree:.4f}")
-    assert lin_agree > 0.9 and clu_agree > 0.9
+    assert lin_agree > 0.99 and clu_agree > 0.93         # measured 0.996 / 0.947
+
+
+def test_fused_block_kernels_meet_the_golden_fixture_directly(wrapper, pkg, golden, dev):
+    """G5 again with the fused block-tail kernel forced on (it is otherwise used from 384 row tiles up, and
+    4 x 1601 rows are 51): the kernel that dominates the benchmark step is compared with the reference's
+    outputs directly, not only through its bit-identity with the per-GEMM route."""
+    import ctypes
+    g = golden("g5_scfg_b4_320")
+    lib = pkg.native.load_library()
+    img = pkg.synth.synth_images(4, 320, 320, seed=0).to(dev)
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1])   # noqa: E731
+    with torch.no_grad():
+        code_a, _q, (_s, _z, idx_a), _o = wrapper.model(img=img)
+        lib.equss_dev_fuse_min_tiles(ctypes.c_int(1))
+        try:
+            pkg.native.profile_enable(256)
+            code_b, _q, (_s, _z, idx_b), _o = wrapper.model(img=img)
+            feat_b = wrapper.model.extractor(img)
+            prof = pkg.native.profile_read(reset=True)
+        finally:
+            pkg.native.profile_enable(0)
+            lib.equss_dev_fuse_min_tiles(ctypes.c_int(384))
+    assert prof["block_tail"][1] == 24 and prof["gemm_fc1"][1] == 0       # 12 fused launches per ViT pass
+    tok = g["tok"]
+    assert _rel_l2(rows(feat_b)[tok].cpu().numpy(), g["feat_tok"]) < FEAT_REL_L2
+    assert _rel_l2(rows(code_b)[tok].cpu().numpy(), g["code_tok"]) < CODE_REL_L2
+    agree = float((idx_b.cpu().numpy() == g["index"].astype(np.int64)).mean())
+    print("fused route: end-to-end code-index agreement with the fp32 reference", agree)
+    assert agree > 0.985
+    assert torch.equal(code_a, code_b) and torch.equal(idx_a, idx_b)       # both routes give a row the same bits
 
 
 def test_quantized_output_matches_reference_where_indices_agree(wrapper, pkg, golden, dev):
