@@ -34,6 +34,18 @@ def _headers():
     return hdrs
 
 
+def source_digest():
+    """sha256 (first 16 hex digits) over the kernel sources and headers, in name order: identifies the
+    code a measurement (profiles/pmc_traffic.json) was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for path in sorted([os.path.join(CSRC, f) for f in _sources()] + _headers()):
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

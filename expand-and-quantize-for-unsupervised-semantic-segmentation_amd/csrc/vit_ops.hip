@@ -364,6 +364,19 @@ int patch_tokens(const float* img, const void* w_patch, const float* b_patch, co
 
 }  // namespace
 
+namespace equss {
+// fp32-only entry points for the fp32 parity forward (parity_f32.hip)
+int layernorm_f32(const float* x, int64_t ld_x, const float* gamma, const float* beta, float* out, int rows, int C,
+                  int tokens, float eps, hipStream_t s) {
+    return layernorm(x, ld_x, gamma, beta, nullptr, C, out, rows, C, tokens, eps, s);
+}
+int assemble_tokens_f32(const float* patch, const float* cls, const float* pos, float* x, int B, int n, int C, hipStream_t s) {
+    const long items = (long)B * (n + 1) * (C / 4);
+    hipLaunchKernelGGL(assemble_tokens_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, s, patch, cls, pos, x, n, C, items);
+    return check_launch("assemble_tokens_kernel");
+}
+}  // namespace equss
+
 extern "C" int equss_layernorm_bf16(const float* x, int64_t ld_x, const float* gamma, const float* beta,
                                     void* out_bf16, int64_t ld_out, float* out_f32, int rows, int C,
                                     int tokens_per_image, float eps, void* stream) {

@@ -84,7 +84,12 @@ class VisionTransformer(nn.Module):
                 nn.init.constant_(m.weight, 1.0)
         self._handle = None
         self._handle_key = None
+        self._handle32 = None
+        self._handle32_key = None
         self._pos_cache = {}
+        # "bf16": bf16 MFMA operands, fp32 accumulation (the throughput path); "fp32": every product and sum
+        # in fp32 (parity mode: comparable with the reference's fp32 CPU run element by element)
+        self.precision = "bf16"
 
     # -- position embedding -----------------------------------------------------------------------
     def interpolate_pos_encoding(self, npatch, w, h):
@@ -120,37 +125,47 @@ class VisionTransformer(nn.Module):
         alone; ordinary in-place writes, load_state_dict and .to() are noticed without it."""
         self._handle = None
         self._handle_key = None
+        self._handle32 = None
+        self._handle32_key = None
         self._pos_cache = {}
 
     # -- device weight set ------------------------------------------------------------------------
     def _weights_key(self):
         return tuple((p.data_ptr(), p._version) for p in self.parameters())
 
-    def device_handle(self):
-        """bf16 GEMM weights + fp32 norm/bias vectors in the layout the C ABI wants; rebuilt only when
-        a parameter was modified or moved (the backbone is frozen on this path)."""
+    def device_handle(self, fp32=False):
+        """bf16 (or, for the parity mode, fp32) GEMM weights + fp32 norm/bias vectors in the layout the
+        C ABI wants; rebuilt only when a parameter was modified or moved (the backbone is frozen on this path)."""
         key = self._weights_key()
+        if fp32:
+            if self._handle32 is None or self._handle32_key != key:
+                self._handle32 = self._build_handle(torch.float32)
+                self._handle32_key = key
+            return self._handle32
         if self._handle is None or self._handle_key != key:
-            dev = self.pos_embed.device
-            f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()        # noqa: E731
-            b16 = lambda t: t.detach().to(dev, torch.bfloat16).contiguous()       # noqa: E731
-            c = self.embed_dim
-            t = {"patch_w": b16(self.patch_embed.proj.weight.reshape(c, -1)),
-                 "patch_b": f32(self.patch_embed.proj.bias),
-                 "cls": f32(self.cls_token.reshape(-1)),
-                 "norm_g": f32(self.norm.weight), "norm_b": f32(self.norm.bias)}
-            for i, blk in enumerate(self.blocks):
-                pre = f"blocks.{i}."
-                qkv_b = blk.attn.qkv.bias if blk.attn.qkv.bias is not None else torch.zeros(3 * c)
-                t[pre + "ln1_g"], t[pre + "ln1_b"] = f32(blk.norm1.weight), f32(blk.norm1.bias)
-                t[pre + "qkv_w"], t[pre + "qkv_b"] = b16(blk.attn.qkv.weight), f32(qkv_b)
-                t[pre + "proj_w"], t[pre + "proj_b"] = b16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
-                t[pre + "ln2_g"], t[pre + "ln2_b"] = f32(blk.norm2.weight), f32(blk.norm2.bias)
-                t[pre + "fc1_w"], t[pre + "fc1_b"] = b16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
-                t[pre + "fc2_w"], t[pre + "fc2_b"] = b16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
-            self._handle = native.VitHandle(t, c, self.depth, self.num_heads, self.patch_embed.patch_size)
+            self._handle = self._build_handle(torch.bfloat16)
             self._handle_key = key
         return self._handle
+
+    def _build_handle(self, gemm_dtype):
+        dev = self.pos_embed.device
+        f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()        # noqa: E731
+        b16 = lambda t: t.detach().to(dev, gemm_dtype).contiguous()   # noqa: E731  (GEMM operands)
+        c = self.embed_dim
+        t = {"patch_w": b16(self.patch_embed.proj.weight.reshape(c, -1)),
+             "patch_b": f32(self.patch_embed.proj.bias),
+             "cls": f32(self.cls_token.reshape(-1)),
+             "norm_g": f32(self.norm.weight), "norm_b": f32(self.norm.bias)}
+        for i, blk in enumerate(self.blocks):
+            pre = f"blocks.{i}."
+            qkv_b = blk.attn.qkv.bias if blk.attn.qkv.bias is not None else torch.zeros(3 * c)
+            t[pre + "ln1_g"], t[pre + "ln1_b"] = f32(blk.norm1.weight), f32(blk.norm1.bias)
+            t[pre + "qkv_w"], t[pre + "qkv_b"] = b16(blk.attn.qkv.weight), f32(qkv_b)
+            t[pre + "proj_w"], t[pre + "proj_b"] = b16(blk.attn.proj.weight), f32(blk.attn.proj.bias)
+            t[pre + "ln2_g"], t[pre + "ln2_b"] = f32(blk.norm2.weight), f32(blk.norm2.bias)
+            t[pre + "fc1_w"], t[pre + "fc1_b"] = b16(blk.mlp.fc1.weight), f32(blk.mlp.fc1.bias)
+            t[pre + "fc2_w"], t[pre + "fc2_b"] = b16(blk.mlp.fc2.weight), f32(blk.mlp.fc2.bias)
+        return native.VitHandle(t, c, self.depth, self.num_heads, self.patch_embed.patch_size)
 
     # -- forward ----------------------------------------------------------------------------------
     @torch.no_grad()
@@ -159,6 +174,13 @@ class VisionTransformer(nn.Module):
         img = img.detach().to(torch.float32).contiguous()
         _, _, h, w = img.shape
         pos = self._pos_for(h, w)  # the reference names dims 2,3 "w, h"; the maths is symmetric in them
+        if self.precision == "fp32":
+            f32 = native.vit_forward_f32(self.device_handle(fp32=True), img, pos)
+            if feat_bf16 is not None:
+                feat_bf16.copy_(f32)
+            else:
+                feat_bf16 = f32.to(torch.bfloat16)
+            return (feat_bf16, f32) if want_f32 else feat_bf16
         return native.vit_forward(self.device_handle(), img, pos, feat_bf16=feat_bf16, want_f32=want_f32)
 
     @torch.no_grad()
@@ -171,6 +193,10 @@ class VisionTransformer(nn.Module):
             raise ValueError(f"n={n} must lie in [1, {self.depth}]")
         img = x.detach().to(torch.float32).contiguous()
         _, _, h, w = img.shape
+        if self.precision == "fp32" and n == 1:
+            b = img.shape[0]
+            feat = native.vit_forward_f32(self.device_handle(fp32=True), img, self._pos_for(h, w), keep_cls=True)
+            return [feat.reshape(b, -1, self.embed_dim)], [], []
         feats = native.vit_intermediate_feat(self.device_handle(), img, self._pos_for(h, w), n_last=n)
         return [feats[i] for i in range(n)], [], []
 

@@ -62,53 +62,66 @@ class UnSegMetrics(nn.Module):
         counts = torch.bincount(key, minlength=self.num_classes * n_pred + 1)[:-1]
         self.confusion_matrix += counts.reshape(self.num_classes, n_pred).t()
 
+    def _match(self, cm_cpu: torch.Tensor):
+        """One-to-one (cluster row, class column) pairs that maximise the matched pixel count (metric.py:66)."""
+        rows, cols = linear_sum_assignment(cm_cpu.numpy(), maximize=True)
+        return rows, cols
+
+    def _aligned_histogram(self, cm: torch.Tensor) -> torch.Tensor:
+        """The confusion matrix with its prediction rows brought into class order, square, so that the
+        diagonal holds the true positives (metric.py:65-86)."""
+        k = self.num_classes
+        if not self.compute_hungarian:              # linear probe: predictions already are class ids
+            ident = torch.arange(k).unsqueeze(1)
+            self.assignments = (ident, ident.clone())
+            return cm
+        cm_cpu = cm.detach().cpu()
+        self.assignments = self._match(cm_cpu)
+        if self.extra_classes == 0:
+            # row r was matched to class assignments[1][r]; sorting the rows by their class aligns them
+            order = np.argsort(self.assignments[1])
+            return cm[order, :]
+        # more clusters than classes: every class picks its cluster (the matching of the transposed
+        # problem), the clusters nobody picked are pooled into one extra row, and a zero column keeps the
+        # matrix square (metric.py:70-82)
+        _classes, picked = self._match(cm_cpu.t())
+        matched = set(int(r) for r in self.assignments[0])
+        pooled = [r for r in range(k + self.extra_classes) if r not in matched]
+        rows = [cm[picked, :], cm[pooled, :].sum(dim=0, keepdim=True)]
+        square = torch.cat(rows, dim=0)
+        pad = torch.zeros(k + 1, 1, device=square.device)
+        return torch.cat([square, pad], dim=1)
+
     @torch.no_grad()
     def compute(self, prefix: str = None) -> Dict[str, torch.Tensor]:
-        """mIoU and pixel accuracy in percent (metric.py:60-112)."""
+        """mIoU and pixel accuracy in percent (metric.py:60-112): the confusion matrix is summed over the
+        ranks (one all-reduce), aligned, and read off its diagonal.  Classes that never occur as label or
+        prediction (0 / 0) are left out of the mean, as the reference's NaN filter does (:92-93)."""
         self.confusion_matrix = all_reduce_tensor(self.confusion_matrix, op="sum")
-        cm = self.confusion_matrix
-        if self.compute_hungarian:
-            self.assignments = linear_sum_assignment(cm.detach().cpu(), maximize=True)
-            if self.extra_classes == 0:
-                self.histogram = cm[np.argsort(self.assignments[1]), :]
-            else:
-                assignments_t = linear_sum_assignment(cm.detach().cpu().t(), maximize=True)
-                histogram = cm[assignments_t[1], :]
-                missing = list(set(range(self.num_classes + self.extra_classes)) - set(self.assignments[0]))
-                histogram = torch.cat([histogram, cm[missing, :].sum(0, keepdim=True)], dim=0)
-                new_col = torch.zeros(self.num_classes + 1, 1, device=histogram.device)
-                self.histogram = torch.cat([histogram, new_col], dim=1)
-        else:
-            ar = torch.arange(self.num_classes).unsqueeze(1)
-            self.assignments = (ar, ar.clone())
-            self.histogram = cm
-
-        tp = torch.diag(self.histogram)
-        fp = torch.sum(self.histogram, dim=0) - tp
-        fn = torch.sum(self.histogram, dim=1) - tp
-        iou = tp / (tp + fp + fn)
-        iou = iou[~torch.isnan(iou)].mean()
-        accuracy = torch.sum(tp) / torch.sum(self.histogram)
-        output = dict(iou=100 * iou, accuracy=100 * accuracy)
-
+        self.histogram = hist = self._aligned_histogram(self.confusion_matrix)
+        hit = hist.diagonal()
+        union = hist.sum(dim=0) + hist.sum(dim=1) - hit        # tp + fp + fn
+        per_class = hit / union
+        output = dict(iou=100 * per_class[~per_class.isnan()].mean(), accuracy=100 * (hit.sum() / hist.sum()))
         if self.csv_dir is not None:
             import pandas as pd
-            precision = (100 * tp / (tp + fn)).unsqueeze(-1)
+            recall = (100 * hit / hist.sum(dim=1)).unsqueeze(-1)
             os.makedirs(self.csv_dir, exist_ok=True)
-            pd.DataFrame(torch.cat([self.histogram, precision], dim=1).cpu().numpy()).to_csv(
-                os.path.join(self.csv_dir, f"{prefix}_7.csv"))
+            pd.DataFrame(torch.cat([hist, recall], dim=1).cpu().numpy()).to_csv(os.path.join(self.csv_dir, f"{prefix}_7.csv"))
         return output
 
     @torch.no_grad()
     def map_clusters(self, clusters):
-        """Cluster id -> matched class id, -1 for unmatched extra clusters (metric.py:114-124)."""
-        if self.extra_classes == 0:
-            return torch.tensor(self.assignments[1])[clusters]
-        missing = sorted(set(range(self.num_classes + self.extra_classes)) - set(self.assignments[0]))
-        cluster_to_class = self.assignments[1]
-        for entry in missing:
-            if entry == cluster_to_class.shape[0]:
-                cluster_to_class = np.append(cluster_to_class, -1)
-            else:
-                cluster_to_class = np.insert(cluster_to_class, entry + 1, -1)
-        return torch.tensor(cluster_to_class)[clusters]
+        """Cluster id -> matched class id, -1 for clusters no class was matched to (metric.py:112-125).
+        Needs a compute() with compute_hungarian first.  The table is laid out as the reference lays it
+        out: the matched classes in cluster order, with a -1 spliced in one position AFTER each unmatched
+        cluster id (or appended when that id is the current length).  With unmatched clusters only at the
+        end, which is what update() produces (it drops predictions >= num_classes, :49), that is the plain
+        lookup table."""
+        table = [int(c) for c in self.assignments[1]]
+        if self.extra_classes:
+            matched = set(int(r) for r in self.assignments[0])
+            for cluster in range(self.num_classes + self.extra_classes):
+                if cluster not in matched:
+                    table.insert(cluster if cluster == len(table) else cluster + 1, -1)
+        return torch.tensor(table, dtype=torch.long)[clusters]

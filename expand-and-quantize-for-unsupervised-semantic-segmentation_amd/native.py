@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = [
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_block_tail_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
+    "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
     "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
 ]
 
@@ -103,6 +104,13 @@ def _declare(lib):
     lib.equss_vit_intermediate_feat.restype = c_int
     lib.equss_vit_intermediate_feat.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_vp, c_vp, c_int, c_vp, c_vp, c_sz,
                                                 c_int, c_int, c_int, c_vp]
+    lib.equss_vit_f32_workspace_bytes.restype = c_sz
+    lib.equss_vit_f32_workspace_bytes.argtypes = [ctypes.POINTER(VitStruct), c_int, c_int, c_int]
+    lib.equss_vit_forward_f32.restype = c_int
+    lib.equss_vit_forward_f32.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_vp, c_vp, c_int, c_vp, c_sz,
+                                          c_int, c_int, c_int, c_vp]
+    lib.equss_expand_head_f32.restype = c_int
+    lib.equss_expand_head_f32.argtypes = [c_vp] * 9 + [c_int, c_int, c_int, c_vp]
     lib.equss_expand_head.restype = c_int
     lib.equss_expand_head.argtypes = [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_vp]
     lib.equss_probe_workspace_bytes.restype = c_sz
@@ -145,6 +153,12 @@ def _check(rc, what):
 
 
 def _stream(t):
+    """The current HIP stream of ``t``'s device.  Kernels launch on the CURRENT device, so that device
+    must be the tensor's: a launch with a foreign device's pointers and stream handle would corrupt
+    memory silently, hence the loud failure (one process per GPU, as torchrun sets it up, never trips it)."""
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise EqussError(f"tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                         f"wrap the call in `with torch.cuda.device({t.device.index}):`")
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
@@ -415,6 +429,37 @@ def vit_intermediate_feat(handle, img, pos, n_last=1, want_taps=False):
                                          _ptr(taps), _ptr(ws), ws.numel(), b, h, w, _stream(img))
     _check(rc, "equss_vit_intermediate_feat")
     return (feats, taps) if want_taps else feats
+
+
+def vit_forward_f32(handle, img, pos, keep_cls=False):
+    """fp32 parity mode: patch features (B*n, C) fp32, or all tokens (B*(1+n), C) with keep_cls.
+    ``handle`` must hold fp32 GEMM weights (VisionTransformer.device_handle(fp32=True))."""
+    lib = load_library()
+    _need_cuda(img, pos)
+    b, _, h, w = img.shape
+    c = handle.embed_dim
+    n = (h // handle.patch) * (w // handle.patch)
+    feat = torch.empty((b * (n + 1 if keep_cls else n), c), dtype=torch.float32, device=img.device)
+    nbytes = lib.equss_vit_f32_workspace_bytes(ctypes.byref(handle.struct), b, h, w)
+    ws = _workspace(img.device, nbytes, "vit_f32")
+    rc = lib.equss_vit_forward_f32(ctypes.byref(handle.struct), _ptr(img), _ptr(pos), _ptr(feat), int(bool(keep_cls)),
+                                   _ptr(ws), ws.numel(), b, h, w, _stream(img))
+    _check(rc, "equss_vit_forward_f32")
+    return feat
+
+
+def expand_head_f32(feat, w1, b1, w2a, b2a, w2b, b2b):
+    """fp32 parity mode of the expansion head: feat (rows, C) fp32 -> code (rows, D) fp32."""
+    lib = load_library()
+    _need_cuda(feat, w1, b1, w2a, b2a, w2b, b2b)
+    rows, c = feat.shape
+    d = w1.shape[0]
+    hidden = torch.empty((rows, c), dtype=torch.float32, device=feat.device)
+    code = torch.empty((rows, d), dtype=torch.float32, device=feat.device)
+    rc = lib.equss_expand_head_f32(_ptr(feat), _ptr(w1), _ptr(b1), _ptr(w2a), _ptr(b2a), _ptr(w2b), _ptr(b2b),
+                                   _ptr(hidden), _ptr(code), rows, c, d, _stream(feat))
+    _check(rc, "equss_expand_head_f32")
+    return code
 
 
 def expand_head(fh, w2a, b2a, w_cat, b_cat, out_dim, out=None):

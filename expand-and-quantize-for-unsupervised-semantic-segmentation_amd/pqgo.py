@@ -570,9 +570,31 @@ class DIONPQGO(nn.Module):
             self._head_key = key
         return self._head
 
+    @property
+    def precision(self) -> str:
+        """"bf16" (default): bf16 MFMA operands with fp32 accumulation in the ViT and the head, the
+        throughput path.  "fp32": parity mode, every product and sum of the eval forward in fp32, so that
+        `code` agrees with the reference's fp32 CPU run to ~1e-6 and the code indices agree outside exact
+        near-ties.  The PQ assign is exact fp32 in both."""
+        return self.extractor.backbone.precision
+
+    @precision.setter
+    def precision(self, value: str) -> None:
+        if value not in ("bf16", "fp32"):
+            raise ValueError(f"Unsupported precision {value}")
+        self.extractor.backbone.precision = value
+
     @torch.no_grad()
     def _code_rows(self, img, want_feat=False):
         """img -> (code rows (b*n, D) fp32, feat (b*n, C) fp32 or None) through the HIP ViT and head."""
+        if self.precision == "fp32":
+            _bf, feat32 = self.extractor.forward_tokens(img, want_f32=True)
+            ps = [self.cluster1[0].weight, self.cluster1[0].bias, self.cluster2[0].weight, self.cluster2[0].bias,
+                  self.cluster2[2].weight, self.cluster2[2].bias]
+            c, d = self.feat_dim, self.hidden_dim
+            w1, b1, w2a, b2a, w2b, b2b = [p.detach().float().contiguous() for p in ps]
+            code = native.expand_head_f32(feat32, w1.reshape(d, c), b1, w2a.reshape(c, c), b2a, w2b.reshape(d, c), b2b)
+            return code, (feat32 if want_feat else None)
         b, _, h, w = img.shape
         p = self.extractor.patch_size
         n = (h // p) * (w // p)
@@ -645,7 +667,8 @@ class DIONPQGO(nn.Module):
         p = self.extractor.patch_size
         gh, gw = h // p, w // p
         if not self.training:
-            if self.eval_streams > 1 and img.is_cuda and b >= self.eval_streams * self.eval_stream_min_images:
+            if (self.eval_streams > 1 and img.is_cuda and b >= self.eval_streams * self.eval_stream_min_images
+                    and self.precision == "bf16"):
                 return self._forward_eval_streams(img)
             code_rows, _ = self._code_rows(img)
             code = _nchw_of(code_rows, b, gh, gw)

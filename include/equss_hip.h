@@ -247,6 +247,23 @@ int equss_vit_intermediate_feat(const EqussVit* vit, const float* img, const flo
                                 int n_last, float* x_taps, void* workspace, size_t workspace_bytes,
                                 int B, int H, int W, void* stream);
 
+/* fp32 parity mode of the same forward: every GEMM, the attention and the head evaluated in fp32
+ * (exact fp32 products, fp32 accumulation; erff GELU; expf softmax), so that features, `code` and with
+ * them the code indices can be compared with the reference's fp32 CPU run element by element.  Same
+ * reference lines as equss_vit_forward / equss_expand_head; built for comparison, not for throughput.
+ *   vit: an EqussVit whose *_w pointers address FP32 matrices in the same [out, in] layouts
+ *   feat (B*n, C) fp32 out, or (B*(1+n), C) with the CLS rows when keep_cls != 0
+ *   workspace: equss_vit_f32_workspace_bytes() bytes, 256-byte aligned. */
+size_t equss_vit_f32_workspace_bytes(const EqussVit* vit, int B, int H, int W);
+int equss_vit_forward_f32(const EqussVit* vit, const float* img, const float* pos, float* feat, int keep_cls,
+                          void* workspace, size_t workspace_bytes, int B, int H, int W, void* stream);
+/*   feat (rows, C) fp32; w1 (D, C), w2a (C, C), w2b (D, C) fp32 with their biases; hidden (rows, C) fp32
+ *   scratch; code (rows, D) fp32 out = (f W1^T + b1) + (relu(f W2a^T + b2a) W2b^T + b2b), the reference's
+ *   order of additions (dino_pqgo.py:127-128). */
+int equss_expand_head_f32(const float* feat, const float* w1, const float* b1, const float* w2a, const float* b2a,
+                          const float* w2b, const float* b2b, float* hidden, float* code, int rows, int C, int D,
+                          void* stream);
+
 /* Expansion head (model/dino_pqgo.py:104-112,:127-128):
  *   code = W1 f + b1 + W2b relu(W2a f + b2a) + b2b, evaluated as two GEMMs:
  *   h = relu(f W2a^T + b2a) written beside f, then code = [f | h] [W1 | W2b]^T + (b1 + b2b).

@@ -331,13 +331,20 @@ def probe_and_metric_fixtures(manifest, tmp):
     cwd = os.getcwd()
     os.chdir(tmp)  # the reference's compute() writes ./class_matrix/... as a side effect
     try:
-        for name, (ncls, extra, hung) in {"cluster": (27, 0, True), "linear": (27, 0, False), "extra": (6, 3, True)}.items():
+        for name, (ncls, extra, hung) in {"cluster": (27, 0, True), "linear": (27, 0, False), "extra": (6, 3, True),
+                                          "extra_mid": (4, 3, True)}.items():
             rng = np.random.Generator(np.random.PCG64(100 + ncls + extra + int(hung)))
             label = torch.from_numpy(rng.integers(-1, ncls, size=(2, 48, 48)).astype(np.int64))
             # predictions correlated with a permutation of the labels so that the assignment matters
             perm = torch.from_numpy(rng.permutation(ncls))
+            if name == "extra_mid":   # classes land on clusters 1, 3, 4, 6: the unmatched clusters 0, 2, 5 lie in between
+                perm = torch.tensor([3, 6, 1, 4])
             noise = torch.from_numpy(rng.integers(0, ncls + extra, size=(2, 48, 48)).astype(np.int64))
             keep = torch.from_numpy(rng.random((2, 48, 48)) < 0.6)
+            if name == "extra_mid":
+                # UnSegMetrics.update drops predictions >= num_classes (metric.py:49), so clusters 4..6 never
+                # reach the confusion matrix; keep the matrix informative for clusters 0..3
+                noise = noise.clamp(max=ncls + extra - 1)
             preds = torch.where(keep & (label >= 0), perm[label.clamp(min=0)], noise)
             m = UnSegMetrics(ncls, extra, hung, torch.device("cpu"))
             m.update(preds[:1], label[:1])

@@ -169,3 +169,30 @@ def test_training_quantiser_gradients_match_autograd(pkg, dev):
     assert float((zq - zq_ref).abs().max()) < 1e-6
     for name, a, b in zip(("rows", "books"), got, ref):
         assert float((a - b).norm() / b.norm()) < 1e-5, name
+
+
+def test_rows_with_nan_or_inf_get_index_zero(native, dev):
+    """Every distance of a row that holds a NaN (or an Inf, which l2 normalisation turns into NaN) is NaN;
+    torch.argmin then returns 0, the first NaN, and so do both kernels.  Finite rows beside it are untouched."""
+    import ctypes
+    rng = np.random.Generator(np.random.PCG64(77))
+    code = torch.from_numpy(rng.standard_normal((48, 1024)).astype(np.float32))
+    books = torch.from_numpy(rng.uniform(-1 / 256, 1 / 256, size=(8, 256, 128)).astype(np.float32))
+    code[5, 130] = float("nan")          # sub-space 1 of row 5
+    code[17, 3] = float("inf")           # sub-space 0 of row 17
+    z = torch.nn.functional.normalize(code.reshape(48, 8, 128), dim=-1)
+    cn = torch.nn.functional.normalize(books, dim=-1)
+    dist = (z ** 2).sum(-1, keepdim=True).permute(1, 0, 2) + (cn ** 2).sum(-1).unsqueeze(1) - 2 * torch.einsum("npd,pkd->pnk", z, cn)
+    want = dist.argmin(dim=-1)
+    assert want[1, 5] == 0 and want[0, 17] == 0
+    for mode in (0, 1):
+        native.load_library().equss_dev_pq_mode(ctypes.c_int(mode))
+        try:
+            idx, zq, loss = native.pq_assign(code.to(dev), books.to(dev))
+        finally:
+            native.load_library().equss_dev_pq_mode(ctypes.c_int(0))
+        got = idx.cpu()
+        assert got[1, 5] == 0 and got[0, 17] == 0
+        mask = torch.ones(8, 48, dtype=torch.bool)
+        mask[1, 5] = mask[0, 17] = False
+        assert torch.equal(got[mask], want[mask])

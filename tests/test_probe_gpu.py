@@ -108,7 +108,7 @@ def test_full_scale_probe_properties(pkg, native, dev):
     assert torch.equal(losses, losses2) and torch.equal(lin, lin2) and torch.equal(clu, clu2)
 
 
-@pytest.mark.parametrize("name", ["cluster", "linear", "extra"])
+@pytest.mark.parametrize("name", ["cluster", "linear", "extra", "extra_mid"])
 def test_metrics_on_device_match_reference_fixture(name, pkg, golden, dev):
     from importlib import import_module
     metric = import_module(pkg.__name__ + ".metric")

@@ -1,15 +1,18 @@
 """Condense rocprofv3 output (kernel-trace stats + separate FETCH_SIZE / WRITE_SIZE passes of the
 same bench.py command) into the small files kept under profiles/.
 usage: python tools/profile_summary.py <gpurun_out/prof_dir> <tag>"""
-import collections, csv, glob, json, os, sys
+import collections, csv, glob, importlib, json, os, sys
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, root)
+source_digest = importlib.import_module("expand-and-quantize-for-unsupervised-semantic-segmentation_amd.build").source_digest()
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
 CLASS = [("mlp_kernel<true", "block_tail"), ("mlp_kernel", "mlp_fused"), ("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
-         ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"),
+         ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"), ("gemm8_kernel<101,", "patch_gemm+pos+ln"),
+         ("cls_rows_kernel", "patch_cls_rows"), ("probe_", "probes"), ("confusion_", "confusion"),
          ("layernorm_rowtile_kernel", "layernorm_tail(proj,fc2)"), ("layernorm_kernel", "layernorm"),
          ("gemm8_kernel<1,", "gemm_fc1"), ("gemm8_kernel<0,", "gemm_bf16out"), ("gemm8_kernel<2,", "head_gemm1"),
          ("gemm8_kernel<3, 256", "head_gemm2"), ("gemm8_kernel<3, 128", "patch_gemm"),
@@ -63,7 +66,7 @@ for cls, t in traffic.items():
     summary[cls] = {"hbm_read_bytes_per_launch": round(fetch), "hbm_write_bytes_per_launch": round(write),
                     "hbm_bytes_per_launch": round(fetch + write), "launches_sampled": t["launches_f"]}
 with open(os.path.join(out, f"{tag}_pmc_traffic.json"), "w") as f:
-    json.dump({"note": "FETCH_SIZE and WRITE_SIZE from two separate rocprofv3 --pmc passes of bench.py; "
+    json.dump({"source_digest": source_digest, "note": "FETCH_SIZE and WRITE_SIZE from two separate rocprofv3 --pmc passes of bench.py; "
                        "FETCH_SIZE doubled (gfx950 counts half of a wide coalesced read); bytes per launch",
                "classes": summary}, f, indent=1, sort_keys=True)
 flat = {"attention": summary.get("attention", {}).get("hbm_bytes_per_launch"),
@@ -73,6 +76,9 @@ flat = {"attention": summary.get("attention", {}).get("hbm_bytes_per_launch"),
         "block_tail": summary.get("block_tail", {}).get("hbm_bytes_per_launch"),
         "gemm_qkv": summary.get("gemm_bf16out", {}).get("hbm_bytes_per_launch")}
 flat = {k: v for k, v in flat.items() if v is not None}
+# bench.py reports these numbers only while the kernel sources still are the ones they were measured on
+flat["source_digest"] = source_digest
+flat["measured_from"] = tag
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(flat, f, indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1))
