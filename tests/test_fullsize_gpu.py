@@ -87,3 +87,44 @@ def test_streamed_eval_forward_equals_single_stream(pkg, dev):
             assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2][2], ref[2][2]), k
             assert all(torch.equal(a, b) for a, b in zip(got[2][1], ref[2][1]))
             assert abs(float(got[3]["vq-loss"]) - float(ref[3]["vq-loss"])) < 1e-6 * abs(float(ref[3]["vq-loss"])) + 1e-9
+
+
+def test_bcfg_at_its_real_shape_768px(pkg, native, oracle, dev):
+    """ViT-B/8 + 16 x 512 PQ on 2 crops of 768 x 768 (N = 9 217 tokens per image, the shape the configuration
+    is defined by): (a) one attention head at that sequence length against an fp64 softmax(q k^T) v,
+    (b) the PQ indices of the path's own 18 432 code rows against the fp64 arg-min outside near-ties,
+    (c) a batch of two gives each image the bits it gets alone."""
+    import numpy as np
+    from conftest import assert_index_parity
+    cfg = pkg.configs.B_CFG
+    m = pkg.build_model(cfg)
+    state = pkg.synth.synth_pqgo_state(cfg, seed=1234)
+    m.load_state_dict(state, strict=True)
+    m = m.to(dev).eval()
+    m.model.eval_streams = 1
+    img = pkg.synth.synth_images(2, 768, 768, seed=31).to(dev)
+    with torch.no_grad():
+        code, quant, (_s, _q, index), out = m.model(img=img)
+        code, quant, index = code.clone(), quant.clone(), index.clone()
+        for i in range(2):
+            c1, q1, (_a, _b, i1), _o = m.model(img=img[i:i + 1])
+            assert torch.equal(i1, index[:, i:i + 1]) and torch.equal(c1, code[i:i + 1]) and torch.equal(q1, quant[i:i + 1])
+    assert index.shape == (16, 2, 96, 96) and torch.isfinite(code).all()
+    # (b) indices of the path's own code rows
+    rows = code.permute(0, 2, 3, 1).reshape(-1, 2048).cpu().contiguous()
+    books = [state[f"model.vq_blocks.0.quantizers.{i}.embedding.weight"] for i in range(16)]
+    want, gap = oracle.pq_top2_gap(books, rows, "l2")
+    flips = assert_index_parity(index.reshape(16, -1).cpu().numpy(), want.numpy(), gap.numpy(), "B-cfg 768px own code")
+    print("B-cfg 2 x 768^2: near-tie flips on own code:", flips, "of", want.numel())
+    # (a) attention at N = 9217: 12 heads computed, head 5 of image 1 checked in fp64
+    n, heads = 9217, 12
+    gen = torch.Generator(device="cpu").manual_seed(9)
+    qkv = (torch.randn(2 * n, 3 * heads * 64, generator=gen) * 1.5).to(torch.bfloat16).to(dev)
+    got = native.attention_bf16(qkv, 2, n, heads, 0.125)
+    h = 5
+    blk = qkv[n:2 * n].double().reshape(n, 3, heads, 64)
+    q, k, v = blk[:, 0, h], blk[:, 1, h], blk[:, 2, h]
+    ref = torch.softmax((q @ k.t()) * 0.125, dim=-1) @ v
+    err = float((got[n:2 * n, h * 64:(h + 1) * 64].double() - ref).norm() / ref.norm())
+    print("attention at N = 9217, rel-L2 vs fp64:", err)
+    assert err < 1e-2
