@@ -257,11 +257,16 @@ __global__ __launch_bounds__(kPqThreads, 2) void pq_assign_kernel(const PqArgs a
 // in exact arithmetic.
 //
 // Each wave works alone on 16-row tiles (no workgroup barrier in the loop): rows HBM -> registers
-// (next tile prefetched) -> normalise -> fp16 B fragments through a private 4 KiB LDS tile; the fp16
-// codebook of the sub-space sits in LDS (A operand, conflict-free ds_read_b128); pass 1 finds the
-// best score per row, pass 2 recomputes the scores into a per-lane bit mask of survivors (branch
-// free); a single survivor is the answer, several are listed per row and scored in exact fp32 by a
-// half-wave each, straight from the row registers.
+// (the next tile is requested after the MFMA passes, so that it occupies registers only while the
+// latency-bound tail of the tile runs) -> normalise -> fp16 B fragments through a private 4 KiB LDS
+// tile; the fp16 codebook of the sub-space sits in LDS (A operand, conflict-free ds_read_b128); pass 1
+// finds the best score per row, pass 2 recomputes the scores into a per-lane bit mask of survivors
+// (branch free, two instructions per score); a single survivor is the answer, several are listed per
+// row and scored in exact fp32 by a half-wave each, straight from the row registers; the chosen raw
+// codewords of the whole tile are gathered in one L2 round trip.
+// The kernel is bound by vector-instruction issue and latency, not by the matrix pipe (17 % busy) or
+// LDS: per 16-row tile a wave issues ~990 vector instructions (it was 1470 with IEEE division / square
+// root sequences and compare-select masks), 128 MFMAs and 128 fragment reads.
 // ---------------------------------------------------------------------------------------------
 // Sum over the 32 lanes that hold one row: four DPP adds (quad swaps, half-row and row mirrors)
 // cover 16 lanes without touching the LDS crossbar, one shuffle joins the two 16-lane rows.
@@ -273,12 +278,49 @@ __device__ __forceinline__ float row32_sum(float x) {
     return x + __shfl_xor(x, 16, 64);
 }
 
+// Row normalisation of the screened kernel, x / max(|x|, 1e-12), without the compiler's IEEE sequences
+// (17 instructions per square root, 11 per division: they were a third of this kernel's vector
+// instructions, and the kernel is bound by how many of those a SIMD can issue).
+//  * sqrt_rn: v_sqrt_f32 (1 ulp) moved to the correctly rounded result by the usual test of its two
+//    neighbours; no pre-scaling of tiny arguments, because below 1e-24 the 1e-12 floor replaces the root.
+//  * the quotients share one reciprocal (v_rcp_f32 + a Newton step, < 1 ulp) and are one multiply each,
+//    faithful to ~1 ulp.  The norm itself is already summed in this kernel's own order (a lane tree), so a
+//    normalised element equals the reference's only to an ulp or two either way; the distances that
+//    decide an index are exact fp32 functions of these normalised values, as before.
+__device__ __forceinline__ float sqrt_rn(float x) {
+    const float s = __builtin_amdgcn_sqrtf(x);
+    const float lo = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u);
+    const float hi = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float r_lo = fmaf(-lo, s, x), r_hi = fmaf(-hi, s, x);
+    float out = r_lo <= 0.0f ? lo : s;
+    out = r_hi > 0.0f ? hi : out;
+    return (x == 0.0f || x == __builtin_inff()) ? x : out;
+}
+__device__ __forceinline__ float shared_rcp(float den) {
+    const float r = __builtin_amdgcn_rcpf(den);
+    return fmaf(fmaf(-den, r, 1.0f), r, r);
+}
+
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // two fp32 -> one dword of two fp16, round to nearest even
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
     const f16x2 v = {(_Float16)lo, (_Float16)hi};
     return __builtin_bit_cast(uint32_t, v);
+}
+
+#ifdef EQUSS_PQ_STAMPS   // developer build (tools/ubench/pq_stamps.hip): 100 MHz clock at the phase boundaries of one wave
+__device__ unsigned long long g_pq_stamps[64 * 8];
+#define PQ_STAMP(ph) do { if (stamp_it < 64 && wave_g == 37 && lane == 0 && blockIdx.y == 3) g_pq_stamps[stamp_it * 8 + (ph)] = wall_clock64(); } while (0)
+#else
+#define PQ_STAMP(ph) do { } while (0)
+#endif
+
+// mask = 2 mask + (d < 0): the sign bit of d = score - threshold shifted into the mask by one
+// v_alignbit_b32 ((mask:d) >> 31), with no compare, no VCC and no select.  A survivor (d >= 0, including
+// +0 from score == threshold) therefore shows as a ZERO bit; the caller inverts the finished word.
+__device__ __forceinline__ uint32_t shift_in_sign(uint32_t mask, float d) {
+    return __builtin_amdgcn_alignbit(mask, __builtin_bit_cast(uint32_t, d), 31);
 }
 
 constexpr int kScrCap = 8;      // survivors listed per row; more -> exact scan of all K for that row
@@ -297,6 +339,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
     constexpr int RPI = 64 / LPR;         // rows per wave-wide load
     constexpr int NI = kScrRows / RPI;    // float4 per lane per tile
     constexpr int KB = D / 32;            // MFMA k blocks
+    constexpr int GB = NI;                // codeword gathers in flight per lane
     constexpr int ROWB = D * 2;           // bytes per fp16 row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -326,7 +369,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
     }
     for (int k = tid; k < K; k += kScrThreads) {
         const float sq = a.csq[(size_t)p * K + k];
-        csq_s[k] = sq;
+        csq_s[k] = -0.5f * sq;      // the accumulators' start value; |cn|^2 itself is -2 x this, exactly
         cmax2 = fmaxf(cmax2, sq);
     }
     cmax2 = equss::group_max<64>(cmax2);
@@ -355,15 +398,23 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
     };
     fetch(wave_g);
 
+#ifdef EQUSS_PQ_STAMPS
+    int stamp_it = -1;
+#endif
     for (int tile = wave_g; tile < a.ntiles; tile += nwaves) {
+#ifdef EQUSS_PQ_STAMPS
+        ++stamp_it;
+#endif
+        PQ_STAMP(0);
         // ---- normalise; fp16 copy -> private LDS tile ----------------------------------------------
         f32x4 cur[NI];
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             // F.normalize(dim=1, eps=1e-12): x / max(||x||, eps)
             f32x4 v = pre[i];
-            const float den = fmaxf(sqrtf(row32_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w)), 1e-12f);
-            v.x = v.x / den; v.y = v.y / den; v.z = v.z / den; v.w = v.w / den;
+            const float den = fmaxf(sqrt_rn(row32_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w)), 1e-12f);
+            const float rden = shared_rcp(den);
+            v.x *= rden; v.y *= rden; v.z *= rden; v.w *= rden;
             cur[i] = v;
             const int r = i * RPI + rsub;
             uint2 pk;
@@ -372,7 +423,6 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
             *reinterpret_cast<uint2*>(zb + r * ROWB + (((c4 >> 1) ^ (r & 15)) * 16) + (c4 & 1) * 8) = pk;
         }
         if (lane < kScrRows) cnt_s[lane] = 0;
-        fetch(tile + nwaves);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS writes are visible to its reads
         // B fragments: lane (j, q) holds zn[j][32 t + 8 q .. + 7]
         f16x8 bf[KB];
@@ -382,8 +432,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
 
         // scores of codeword tile ct: lane (j, q) gets v~ = <zn_j, cn_k> - csq_k / 2 for k = 16 ct + 4 q + e in acc[e]
         auto scores = [&](int ct) {
-            const f32x4 sq = *reinterpret_cast<const f32x4*>(csq_s + ct * 16 + 4 * q);
-            f32x4 acc = {-0.5f * sq.x, -0.5f * sq.y, -0.5f * sq.z, -0.5f * sq.w};
+            f32x4 acc = *reinterpret_cast<const f32x4*>(csq_s + ct * 16 + 4 * q);
             const char* arow = cb_s + (ct * 16 + j) * ROWB;
 #pragma unroll
             for (int t = 0; t < KB; ++t) {
@@ -393,38 +442,50 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
             return acc;
         };
 
+        PQ_STAMP(1);
         // ---- pass 1: best and second-best score per row ------------------------------------------------
         float best = -__builtin_inff();
         for (int ct = 0; ct < K / 16; ct += 2) {
             const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
-            best = fmaxf(fmaxf(best, fmaxf(a0.x, a0.y)), fmaxf(a0.z, a0.w));
-            best = fmaxf(fmaxf(best, fmaxf(a1.x, a1.y)), fmaxf(a1.z, a1.w));
+            best = fmaxf(fmaxf(fmaxf(fmaxf(best, a0.x), a0.y), a0.z), a0.w);   // (chains of three fold into v_max3_f32)
+            best = fmaxf(fmaxf(fmaxf(fmaxf(best, a1.x), a1.y), a1.z), a1.w);
         }
         best = fmaxf(best, __shfl_xor(best, 16, 64));   // the four lanes that share a row
         best = fmaxf(best, __shfl_xor(best, 32, 64));
         // |zn| <= 1 (+ rounding) after l2 normalisation, whatever the row held
         constexpr float zs = 1.0001f;
         const float T = 2.0f * kScrE * sqrtf(zs * cmax2) + 0.5e-5f * (zs + cmax2) + 2e-6f;
-        const float thr = best - T;   // (NaN scores compare false everywhere: the row ends with index 0)
+        const float thr = best - T;
+        // a row that holds a NaN or an Inf normalises to NaN scores, which fmaxf skips: best stays -inf and
+        // the row ends with no survivor, i.e. index 0 (what arg-min over all-NaN distances returns)
+        const bool row_finite = best > -__builtin_inff();
 
+        PQ_STAMP(2);
         // ---- pass 2: recompute the scores; one bit per (codeword of this lane) that survives --------------
-        // Branch-free: mask = 2 mask + (score >= thr), one 32-bit word per 8 codeword tiles (32 codewords
-        // of this lane).  Value n of a word (n = 4 (ct - ct0) + e) ends at bit nv - 1 - n.
+        // Branch-free: two instructions per score (subtract, shift the sign in), one 32-bit word per 8
+        // codeword tiles (32 codewords of this lane).  Value n of a word (n = 4 (ct - ct0) + e) ends at bit
+        // nv - 1 - n.
         const int nct = K / 16;
         uint32_t mk[MW];
 #pragma unroll
-        for (int w = 0; w < MW; ++w) mk[w] = 0u;
+        for (int w = 0; w < MW; ++w) mk[w] = ~0u;   // survivors are shifted in as zero bits; inverted below
 #pragma unroll
         for (int w = 0; w < MW; ++w) {
             const int ct_end = min(nct, 8 * w + 8);
             for (int ct = 8 * w; ct < ct_end; ct += 2) {
                 const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mk[w] = (mk[w] << 1) | (a0[e] >= thr ? 1u : 0u);
+                for (int e = 0; e < 4; ++e) mk[w] = shift_in_sign(mk[w], a0[e] - thr);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mk[w] = (mk[w] << 1) | (a1[e] >= thr ? 1u : 0u);
+                for (int e = 0; e < 4; ++e) mk[w] = shift_in_sign(mk[w], a1[e] - thr);
             }
+            mk[w] = row_finite ? ~mk[w] : 0u;
         }
+        // The next tile's rows are requested only now: they then occupy registers while the survivor
+        // lists, the occasional exact re-scoring and the gather run (several microseconds, enough for the
+        // loads to land), not during the two MFMA passes, whose fragments need the room.
+        fetch(tile + nwaves);
+        PQ_STAMP(3);
         auto codeword = [&](int w, int bit) {   // bit of word w -> codeword index
             const int n = 4 * min(nct - 8 * w, 8) - 1 - bit;
             return 16 * (8 * w + (n >> 2)) + 4 * q + (n & 3);
@@ -457,6 +518,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
+        PQ_STAMP(4);
         // ---- exact fp32 re-scoring of rows with several survivors: a half-wave per row ---------------
         // dist = (|zn|^2 + |cn|^2) - 2 <zn, cn>, smaller distance wins, then smaller index.
         if (__builtin_amdgcn_ballot_w64(total >= 2) != 0) {
@@ -478,8 +540,8 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
                         const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.cn + ((size_t)p * K + k1) * D + 4 * c4);
                         const float dot0 = row32_sum(fmaf(z.x, c0.x, fmaf(z.y, c0.y, fmaf(z.z, c0.z, z.w * c0.w))));
                         const float dot1 = row32_sum(fmaf(z.x, c1.x, fmaf(z.y, c1.y, fmaf(z.z, c1.z, z.w * c1.w))));
-                        const float d0 = (zq + csq_s[k0]) - 2.0f * dot0;
-                        const float d1 = (zq + csq_s[k1]) - 2.0f * dot1;
+                        const float d0 = (zq + -2.0f * csq_s[k0]) - 2.0f * dot0;
+                        const float d1 = (zq + -2.0f * csq_s[k1]) - 2.0f * dot1;
                         if (d0 < bd || (d0 == bd && k0 < bk)) { bd = d0; bk = k0; }
                         if (d1 < bd || (d1 == bd && k1 < bk)) { bd = d1; bk = k1; }
                     }
@@ -492,25 +554,39 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
         if (lane < kScrRows && tile * kScrRows + lane < a.rows)
             a.idx[(size_t)p * a.rows + tile * kScrRows + lane] = (int64_t)fin_s[lane];
 
+        PQ_STAMP(5);
         // ---- gather + straight-through output + mse numerator, from the row registers -----------------
+        // All codeword loads of the tile are issued before the first is used: one L2 round trip per tile
+        // instead of one per row pair.  (A 16-wave, 128-register build with half-tile batches was tried:
+        // it spills and runs 15 % slower than 12 waves at 168 registers.)
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int r = i * RPI + rsub;
-            const int grow = tile * kScrRows + r;
-            if (grow < a.rows) {
-                const int k = fin_s[r];
-                const f32x4 zn = cur[i];
-                const f32x4 e = *reinterpret_cast<const f32x4*>(a.gather + ((size_t)p * K + k) * D + 4 * c4);
-                f32x4 df; df.x = e.x - zn.x; df.y = e.y - zn.y; df.z = e.z - zn.z; df.w = e.w - zn.w;
-                loss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
-                if (a.zq) {
-                    f32x4 o; o.x = zn.x + df.x; o.y = zn.y + df.y; o.z = zn.z + df.z; o.w = zn.w + df.w;
-                    *reinterpret_cast<f32x4*>(a.zq + (size_t)grow * a.ld_zq + (size_t)p * D + 4 * c4) = o;
+        for (int h = 0; h < NI; h += GB) {
+            f32x4 emb[GB];
+#pragma unroll
+            for (int i = 0; i < GB; ++i) {
+                const int k = fin_s[(h + i) * RPI + rsub];
+                emb[i] = *reinterpret_cast<const f32x4*>(a.gather + ((size_t)p * K + k) * D + 4 * c4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GB; ++i) {
+                const int r = (h + i) * RPI + rsub;
+                const int grow = tile * kScrRows + r;
+                if (grow < a.rows) {
+                    const f32x4 zn = cur[h + i];
+                    const f32x4 e = emb[i];
+                    f32x4 df; df.x = e.x - zn.x; df.y = e.y - zn.y; df.z = e.z - zn.z; df.w = e.w - zn.w;
+                    loss += df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+                    if (a.zq) {
+                        f32x4 o; o.x = zn.x + df.x; o.y = zn.y + df.y; o.z = zn.z + df.z; o.w = zn.w + df.w;
+                        *reinterpret_cast<f32x4*>(a.zq + (size_t)grow * a.ld_zq + (size_t)p * D + 4 * c4) = o;
+                    }
                 }
             }
-            if (i & 1) __builtin_amdgcn_sched_barrier(0);   // two gathers in flight, not all eight
+            __builtin_amdgcn_sched_barrier(0);
         }
         asm volatile("" ::: "memory");
+        PQ_STAMP(6);
     }
     // ---- per-workgroup loss partial (fixed order, no atomics) ----------------------------------
     loss = group_sum<64>(loss);
