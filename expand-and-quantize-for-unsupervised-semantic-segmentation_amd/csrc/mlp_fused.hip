@@ -209,7 +209,9 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             for (int mt = 0; mt < 4; ++mt) {
                 const int m = m0 + wm * 64 + mt * 16 + fr;
                 f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#ifndef EQUSS_ABL_NOXLOAD   // (EQUSS_ABL_*: developer builds that leave one cost out, tools/build_ablations.sh; wrong results by design)
                 if (m < g.M) o = *reinterpret_cast<const f32x4*>(g.x + (size_t)m * g.ldx + n);
+#endif
                 acc2[nt][mt] = o;   // (+ bias before the first use below: the loads get the six G1 steps to arrive)
             }
         }
@@ -291,7 +293,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                         const int row = idx / OCH, ch = idx % OCH;
                         const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                         const int m = m0 + wm * 64 + mt * 16 + row;
+#ifndef EQUSS_ABL_NOLN2
                         if (m < g.M) *reinterpret_cast<uint4*>(ln2 + (size_t)m * g.lda + wn * 96 + ch * 8) = d;
+#else
+                        asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w), "v"(m));
+#endif
                     }
                     asm volatile("" ::: "memory");
                 }
@@ -342,8 +348,12 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                     const int row = wm * 64 + mt * 16 + fr;
                     f32x4 v = acc1[nt][mt];
                     v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+#ifndef EQUSS_ABL_NOGELU
                     const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
                     const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
+#else
+                    const equss::gelu_f32x2 g0 = {v.x, v.y}, g1 = {v.z, v.w};
+#endif
                     uint2 pk;
                     pk.x = equss::pack_bf16(g0.x, g0.y);
                     pk.y = equss::pack_bf16(g1.x, g1.y);
@@ -391,7 +401,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             for (int nt = 0; nt < 6; ++nt) {
                 const int n = wn * 96 + nt * 16 + fq * 4;
                 const f32x4 v = acc2[nt][mt];
+#ifndef EQUSS_ABL_NOSTORE
                 if (m < g.M) *reinterpret_cast<f32x4*>(g.x + (size_t)m * g.ldx + n) = v;
+#else
+                asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+#endif
                 s1[mt] += (v.x + v.y) + (v.z + v.w);
                 s2[mt] += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
             }
@@ -431,7 +445,11 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                     const int row = idx / OCH, ch = idx % OCH;
                     const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                     const int m = m0 + wm * 64 + mt * 16 + row;
+#ifndef EQUSS_ABL_NOSTORE
                     if (m < g.M) *reinterpret_cast<uint4*>(g.ln + (size_t)m * g.ld_ln + wn * 96 + ch * 8) = d;
+#else
+                    asm volatile("" :: "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w), "v"(m));
+#endif
                 }
                 asm volatile("" ::: "memory");
             }

@@ -1,0 +1,11 @@
+#!/bin/bash
+# Developer tool: builds of libequss_hip.so with one cost of the fused block-tail kernel removed each
+# (tools/ubench/libabl_<NAME>.so), for tools/tail_bench.py.  Results of such builds are wrong by design.
+set -e
+P=expand-and-quantize-for-unsupervised-semantic-segmentation_amd
+cd "$(dirname "$0")/.."
+OBJS=$(ls $P/build/*.o | grep -v mlp_fused.o)
+for NAME in "$@"; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-value -ffp-contract=on -DEQUSS_ABL_$NAME -c $P/csrc/mlp_fused.hip -o /tmp/mlp_abl_$NAME.o
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o tools/ubench/libabl_$NAME.so $OBJS /tmp/mlp_abl_$NAME.o
+done

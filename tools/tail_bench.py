@@ -1,0 +1,31 @@
+"""Developer micro-benchmark of the fused block-tail kernel (proj + LN2 + MLP + LN) at the benchmark shape.
+EQUSS_LIB=<other build of the library> selects an ablation build (tools/build_ablations.sh)."""
+import importlib, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("expand-and-quantize-for-unsupervised-semantic-segmentation_amd")
+nat = pkg.native
+if os.environ.get("EQUSS_LIB"):
+    nat.LIB_PATH = os.environ["EQUSS_LIB"]
+dev = torch.device("cuda", 0)
+rows = int(sys.argv[1]) if len(sys.argv) > 1 else 768 * 128
+torch.manual_seed(0)
+c, hid = 384, 1536
+mk = lambda *s, sc=1.0: (torch.randn(*s, device=dev) * sc)
+wp = mk(c, c, sc=c ** -0.5).bfloat16(); bp = mk(c)
+w1 = mk(hid, c, sc=c ** -0.5).bfloat16(); b1 = mk(hid)
+w2 = mk(c, hid, sc=hid ** -0.5).bfloat16(); b2 = mk(c)
+g2, be2, g, be = torch.ones(c, device=dev), torch.zeros(c, device=dev), torch.ones(c, device=dev), torch.zeros(c, device=dev)
+att = mk(rows, c).bfloat16()
+x = mk(rows, c)
+for _ in range(3):
+    nat.block_tail_bf16(att, wp, bp, g2, be2, w1, b1, w2, b2, x, g, be)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    nat.block_tail_bf16(att, wp, bp, g2, be2, w1, b1, w2, b2, x, g, be)
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 10 * 1e3
+flops = rows * (2.0 * c * c + 4.0 * c * hid)
+print(f"block_tail {os.environ.get('EQUSS_LIB', 'default'):40s} rows {rows}: {us:7.1f} us  {flops / us / 1e6:6.1f} TF")
