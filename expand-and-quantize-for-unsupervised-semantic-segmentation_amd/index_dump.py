@@ -10,6 +10,8 @@ import os
 import numpy as np
 import torch
 
+from . import native
+
 __all__ = ["CodeIndexDump"]
 
 _HEADER_BYTES = 128   # fixed-size .npy v1.0 header so the shape can be rewritten in place
@@ -68,6 +70,12 @@ class CodeIndexDump:
             raise ValueError("code index does not fit int16")
         hh, ww = label.shape[-2:]
         dev = z_index.device
+        if z_index.is_cuda and label.is_cuda:
+            # one HIP kernel writes the int16 rows directly (no up-sampled int64 intermediate)
+            rows, lab = native.index_rows_i16(z_index.long(), label.long(), self.upsample)
+            self.index.append(rows.cpu().numpy())
+            self.label.append(lab.cpu().numpy())
+            return
         if self.upsample:
             # nearest: source = floor(dst * in / out)   (ATen's nearest for integer scale ratios and beyond)
             ys = (torch.arange(hh, device=dev) * h) // hh

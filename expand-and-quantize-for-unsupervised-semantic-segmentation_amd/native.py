@@ -29,6 +29,7 @@ EXPORTED_SYMBOLS = [
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
     "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
+    "equss_index_rows_i16", "equss_code_usage",
 ]
 
 
@@ -117,6 +118,10 @@ def _declare(lib):
     lib.equss_probe_workspace_bytes.argtypes = [c_int] * 5
     lib.equss_confusion_update.restype = c_int
     lib.equss_confusion_update.argtypes = [c_vp, c_vp, c_vp, c_i64, c_int, c_int, c_vp]
+    lib.equss_index_rows_i16.restype = c_int
+    lib.equss_index_rows_i16.argtypes = [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_code_usage.restype = c_int
+    lib.equss_code_usage.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp]
     lib.equss_probe_eval.restype = c_int
     lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
@@ -544,3 +549,39 @@ def confusion_update(confusion, preds, label, num_classes):
     _check(load_library().equss_confusion_update(_ptr(preds), _ptr(label), _ptr(confusion), preds.numel(),
                                                  int(num_classes), int(confusion.shape[0]), _stream(confusion)),
            "equss_confusion_update")
+
+
+def index_rows_i16(z_index, label, upsample=True):
+    """z_index (num_pq, B, h, w) int64, label (B, H, W) int64 on the GPU -> (rows, num_pq) int16 index table
+    and (rows,) int16 labels (train.py:283-329): rows = B*H*W with ``upsample`` (indices nearest-upsampled
+    to the label size) or B*h*w (labels sampled at the patch positions)."""
+    _need_cuda(z_index, label)
+    if z_index.dtype != torch.int64 or z_index.dim() != 4 or label.dtype != torch.int64 or label.dim() != 3:
+        raise ValueError("index_rows_i16: z_index must be (num_pq, B, h, w) int64 and label (B, H, W) int64")
+    num_pq, b, h, w = z_index.shape
+    if label.shape[0] != b:
+        raise ValueError("index_rows_i16: batch sizes of z_index and label differ")
+    hh, ww = int(label.shape[1]), int(label.shape[2])
+    z_index, label = z_index.contiguous(), label.contiguous()
+    n = b * hh * ww if upsample else b * h * w
+    idx_rows = torch.empty((n, num_pq), dtype=torch.int16, device=z_index.device)
+    lab_rows = torch.empty((n,), dtype=torch.int16, device=z_index.device)
+    _check(load_library().equss_index_rows_i16(_ptr(z_index), _ptr(label), _ptr(idx_rows), _ptr(lab_rows), b, h, w, hh, ww,
+                                               num_pq, int(bool(upsample)), _stream(z_index)), "equss_index_rows_i16")
+    return idx_rows, lab_rows
+
+
+def code_usage(idx, num_codes, out=None):
+    """idx (num_pq, rows) int64 -> counts (num_pq, num_codes) fp32 of how many rows chose each codeword
+    (added into ``out`` when given)."""
+    _need_cuda(idx)
+    if idx.dtype != torch.int64 or idx.dim() != 2:
+        raise ValueError("code_usage: idx must be (num_pq, rows) int64")
+    idx = idx.contiguous()
+    num_pq, rows = idx.shape
+    if out is None:
+        out = torch.zeros((num_pq, num_codes), dtype=torch.float32, device=idx.device)
+    elif out.shape != (num_pq, num_codes) or out.dtype != torch.float32 or not out.is_contiguous():
+        raise ValueError("code_usage: out must be a contiguous (num_pq, num_codes) float32 tensor")
+    _check(load_library().equss_code_usage(_ptr(idx), _ptr(out), rows, num_pq, int(num_codes), _stream(idx)), "equss_code_usage")
+    return out

@@ -288,8 +288,11 @@ def _quantize_rows(rows, books, normalize, beta, book, training, vq_counts, gath
         zq = (zn + (emb - zn).detach()).reshape(n, num_pq * d)
     if training:
         with torch.no_grad():
-            counts = torch.zeros(num_pq, k, dtype=rows.dtype, device=rows.device)
-            counts.scatter_add_(1, idx, torch.ones_like(idx, dtype=rows.dtype))
+            if idx.is_cuda:
+                counts = native.code_usage(idx, k).to(rows.dtype)      # LDS histogram, all sub-spaces in one launch
+            else:
+                counts = torch.zeros(num_pq, k, dtype=rows.dtype, device=rows.device)
+                counts.scatter_add_(1, idx, torch.ones_like(idx, dtype=rows.dtype))
             # one (num_pq, K) message instead of the reference's num_pq separate K-float all-reduces
             # (dino_pqgo.py:673 inside the python loop at :757)
             counts = all_reduce_tensor(counts, op="sum")

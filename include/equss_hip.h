@@ -308,6 +308,24 @@ int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, co
 int equss_confusion_update(const int64_t* preds, const int64_t* label, int64_t* confusion, int64_t n,
                            int num_classes, int num_pred_classes, void* stream);
 
+/* Code-index table for the reference's offline analyses (the NpyAppendArray dump sketched at
+ * train.py:283-329, consumed by cross_entropy.py / edit_distance.py): one int16 row of num_pq indices per
+ * label pixel and the int16 label beside it.
+ *   z_index  (num_pq, B, h, w) int64: DIONPQGO.forward's stacked index maps (model/dino_pqgo.py:152)
+ *   label    (B, H, W) int64
+ *   upsample != 0: every label pixel takes the indices of the patch under it (nearest neighbour, source =
+ *            floor(dst * in / out) as F.interpolate(mode="nearest")): idx_rows (B*H*W, num_pq), lab_rows (B*H*W)
+ *   upsample == 0: the label is sampled at the patch positions instead: (B*h*w, num_pq) and (B*h*w)
+ * idx_rows 16-byte aligned.  Values are narrowed to int16 (codebooks up to 32 767 entries, labels from -1). */
+int equss_index_rows_i16(const int64_t* z_index, const int64_t* label, int16_t* idx_rows, int16_t* lab_rows,
+                         int B, int h, int w, int H, int W, int num_pq, int upsample, void* stream);
+
+/* Codeword usage counts of a quantisation pass: counts[p][k] += |{r : idx[p][r] == k}|, the one-hot sum of
+ * model/dino_pqgo.py:668-672 (model/quantizer.py:159-160, :485-487) for all sub-spaces in one launch.
+ *   idx (num_pq, rows) int64; counts (num_pq, K) fp32, accumulated in place (clear it first for the counts
+ *   of one pass).  Integer counting, so the result does not depend on scheduling.  K <= 8192. */
+int equss_code_usage(const int64_t* idx, float* counts, int64_t rows, int num_pq, int K, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

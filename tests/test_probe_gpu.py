@@ -123,3 +123,45 @@ def test_metrics_on_device_match_reference_fixture(name, pkg, golden, dev):
     assert np.array_equal(m.confusion_matrix.cpu().numpy(), g[f"{name}_confusion"])
     assert abs(float(res["iou"]) - float(g[f"{name}_iou"])) < 1e-4
     assert abs(float(res["accuracy"]) - float(g[f"{name}_accuracy"])) < 1e-4
+
+
+def test_index_dump_rows_and_usage_counts_on_device(pkg, native, dev, tmp_path):
+    """The index-dump kernel (int16 rows for the reference's offline analyses, train.py:283-329) against
+    F.interpolate(mode="nearest") on the index maps, both sampling directions, odd ratios and num_pq with and
+    without a specialised instance; CodeIndexDump with device tensors against the same with host tensors; the
+    usage-count kernel against a bincount per sub-space; get_histogram_count on a device tensor."""
+    import torch.nn.functional as F
+    gen = torch.Generator(device="cpu").manual_seed(4)
+    for num_pq, b, h, w, hh, ww in ((8, 3, 5, 4, 40, 32), (3, 2, 7, 5, 45, 33), (16, 1, 6, 6, 6, 6)):
+        z = torch.randint(0, 512, (num_pq, b, h, w), generator=gen)
+        lab = torch.randint(-1, 27, (b, hh, ww), generator=gen)
+        rows, labs = native.index_rows_i16(z.to(dev), lab.to(dev), upsample=True)
+        up = F.interpolate(z.permute(1, 0, 2, 3).float(), size=(hh, ww), mode="nearest")
+        want = up.reshape(b, num_pq, -1).permute(0, 2, 1).reshape(-1, num_pq).to(torch.int16)
+        assert rows.dtype == torch.int16 and torch.equal(rows.cpu(), want)
+        assert torch.equal(labs.cpu(), lab.reshape(-1).to(torch.int16))
+        rows2, labs2 = native.index_rows_i16(z.to(dev), lab.to(dev), upsample=False)
+        assert torch.equal(rows2.cpu(), z.permute(1, 2, 3, 0).reshape(-1, num_pq).to(torch.int16))
+        down = F.interpolate(lab[:, None].float(), size=(h, w), mode="nearest")[:, 0]
+        assert torch.equal(labs2.cpu(), down.reshape(-1).to(torch.int16))
+    # CodeIndexDump: device path == host path, file by file
+    z = torch.randint(0, 256, (8, 2, 8, 8), generator=gen)
+    lab = torch.randint(-1, 27, (2, 64, 64), generator=gen)
+    for name, zz, ll in (("dev", z.to(dev), lab.to(dev)), ("host", z, lab)):
+        with pkg.CodeIndexDump(str(tmp_path / name), 8) as dump:
+            dump.append(zz, ll)
+            dump.append(zz[:, :1], ll[:1])
+    for suffix in ("_index.npy", "_label.npy"):
+        a, bb = np.load(str(tmp_path / "dev") + suffix), np.load(str(tmp_path / "host") + suffix)
+        assert a.shape == bb.shape and a.dtype == np.int16 and np.array_equal(a, bb)
+    # usage counts
+    idx = torch.randint(0, 256, (8, 100000), generator=gen)
+    idx[3] = 7
+    counts = native.code_usage(idx.to(dev), 256)
+    want = torch.stack([torch.bincount(idx[p], minlength=256) for p in range(8)]).float()
+    assert torch.equal(counts.cpu(), want)
+    native.code_usage(idx.to(dev)[:, :10], 256, out=counts)
+    assert float(counts.sum()) == 8 * 100010
+    hist = pkg.quantizer.get_histogram_count(counts[0], "current")
+    assert hist == pkg.quantizer.get_histogram_count(counts[0].cpu(), "current")
+    assert pkg.quantizer.get_histogram_count(counts[3], "t") == {"t-p10": 0.0, "t-p50": 0.0, "t-p90": 0.0}
