@@ -259,3 +259,44 @@ def test_training_head_matches_fp32_autograd(pkg, dev):
     # (w2a, b2a: the ReLU mask is the bf16 forward's; the ~0.1 % of units close enough to zero to flip
     # against the fp32 forward give a few percent in the norm)
     assert max(errs.values()) < 5e-2, errs
+
+
+def test_eval_loop_miou_parity(wrapper, pkg, oracle, dev):
+    """The eval loop of train.py:259-364 / eval.py:60-110 on a small synthetic set (two batches of two
+    320 x 320 images): wrapper forward -> UnSegMetrics.update -> compute(), against the CPU oracle's loop on
+    the same images.  Cluster mIoU goes through the Hungarian matching, linear mIoU does not.  Weights and
+    labels are synthetic, so the mIoU values are small; what is asserted is that both paths give the same."""
+    cfg = pkg.configs.S_CFG
+    ncls = cfg["num_classes"]
+    state = pkg.synth.synth_pqgo_state(cfg, seed=1234)
+    batches = [(pkg.synth.synth_images(2, 320, 320, seed=200 + i), pkg.synth.synth_labels(2, 320, 320, ncls, seed=200 + i))
+               for i in range(2)]
+    want = {}
+    conf = {"cluster": torch.zeros(ncls, ncls, dtype=torch.long), "linear": torch.zeros(ncls, ncls, dtype=torch.long)}
+    ref_preds = []
+    for img, label in batches:
+        _t, _o, (o_lin, o_clu), _f, _i = oracle.wrapper_forward(state, img, label, cfg)
+        conf["cluster"] += oracle.metrics_confusion(o_clu, label, ncls)
+        conf["linear"] += oracle.metrics_confusion(o_lin, label, ncls)
+        ref_preds.append((o_lin, o_clu))
+    want["cluster"] = float(oracle.metrics_compute(conf["cluster"], True, ncls)[0])
+    want["linear"] = float(oracle.metrics_compute(conf["linear"], False, ncls)[0])
+    try:
+        for precision, miou_tol, agree_floor in (("fp32", 2e-3, 0.9995), ("bf16", 0.05, 0.93)):
+            wrapper.model.precision = precision
+            cluster_m = pkg.UnSegMetrics(ncls, cfg["eval"]["extra_classes"], True, dev)
+            linear_m = pkg.UnSegMetrics(ncls, 0, False, dev)
+            agree = []
+            with torch.no_grad():
+                for (img, label), (o_lin, o_clu) in zip(batches, ref_preds):
+                    _total, _out, (lin_p, clu_p), _f = wrapper(img.to(dev), img.to(dev), label.to(dev))
+                    cluster_m.update(clu_p, label.to(dev))
+                    linear_m.update(lin_p, label.to(dev))
+                    agree.append((float((lin_p.cpu() == o_lin).float().mean()), float((clu_p.cpu() == o_clu).float().mean())))
+            got_c, got_l = float(cluster_m.compute("cluster")["iou"]), float(linear_m.compute("linear")["iou"])
+            print(f"{precision}: cluster mIoU {got_c:.4f} (oracle {want['cluster']:.4f}), linear mIoU {got_l:.4f} "
+                  f"(oracle {want['linear']:.4f}), pixel agreement linear/cluster {agree}")
+            assert abs(got_c - want["cluster"]) < miou_tol and abs(got_l - want["linear"]) < miou_tol
+            assert min(min(a) for a in agree) > agree_floor
+    finally:
+        wrapper.model.precision = "bf16"
