@@ -84,6 +84,39 @@ __device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
     return __builtin_elementwise_fma(-a, e, relu);
 }
 
+// LDS stores the compiler's wait-count pass does not see.  After a global_load_lds_* the compiler puts
+// s_waitcnt vmcnt(0) in front of every LDS store it emits, because the DMA's destination might alias it; in the
+// ring kernels that drains every stage in flight and every global store the wave has issued, at each epilogue.
+// Callers use these only for rows that are no DMA target while stages are in flight (staging rows of a
+// consumed slot, the hidden-activation tile, the row-statistics exchange).  LDS operations of one wave
+// execute in order, so a later load of the same wave sees the data; other waves need lgkmcnt(0) + a barrier.
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) void*)p;
+}
+__device__ __forceinline__ void lds_store_b64(void* p, uint32_t lo, uint32_t hi) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = {lo, hi};
+    asm volatile("ds_write_b64 %0, %1" ::"v"(lds_addr(p)), "v"(v) : "memory");
+}
+// 16-byte LDS load the wait-count pass does not see (the first LDS load it emits itself after a global_load_lds_*
+// gets the same s_waitcnt vmcnt(0)).  The data is in the returned registers only after lds_wait(registers).
+typedef uint32_t lds_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ lds_u32x4 lds_load_b128(const void* p) {
+    lds_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(lds_addr(p)) : "memory");
+    return v;
+}
+// (the registers pass through the wait as in/out operands: arithmetic on them cannot be scheduled above it)
+template <int N>
+__device__ __forceinline__ void lds_wait(lds_u32x4 (&d)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(d[i]));
+}
+__device__ __forceinline__ void lds_store_f32x2(void* p, float a, float b) {
+    lds_store_b64(p, __builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
+}
+
 template <int WIDTH>
 __device__ __forceinline__ float group_sum(float v) {  // sum over WIDTH consecutive lanes
 #pragma unroll

@@ -104,7 +104,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((row >> 2) & 3); };
+    // 16-B chunk swizzle of a tile row.  128-B rows: (row >> 1) & 7.  64-B rows: a ds_read_b128 is served in the
+    // lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32), so one group reads rows r, r + 12 at chunk fq
+    // and rows r + 4, r + 8 at chunk fq ^ 1 of every bank quarter; the permutation 0,2,3,1 of (row >> 2) & 3
+    // puts those four on four different 16-B columns (the identity left them two and two on the same banks).
+    auto swz = [](int row) { return CPR == 8 ? ((row >> 1) & 7) : ((0x78 >> (2 * ((row >> 2) & 3))) & 3); };
 
     const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
     const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
@@ -324,7 +328,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                 }
                 s1[mt] += __shfl_xor(s1[mt], 16, 64); s2[mt] += __shfl_xor(s2[mt], 16, 64);
                 s1[mt] += __shfl_xor(s1[mt], 32, 64); s2[mt] += __shfl_xor(s2[mt], 32, 64);
-                if (fq == 0) red_s[(wm * TM + mt * 16 + fr) * WN + wn] = make_float2(s1[mt], s2[mt]);
+                if (fq == 0) equss::lds_store_f32x2(red_s + ((wm * TM + mt * 16 + fr) * WN + wn), s1[mt], s2[mt]);
             }
             if (g.ln) {
                 const int free_slot = c_buf == 0 ? S - 1 : c_buf - 1;
@@ -351,7 +355,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                             uint2 pk;
                             pk.x = equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y));
                             pk.y = equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w));
-                            *reinterpret_cast<uint2*>(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
+                            equss::lds_store_b64(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2, pk.x, pk.y);
                         }
                     }
                     asm volatile("" ::: "memory");
@@ -396,6 +400,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
             char* stg = smem + free_slot * kStageBytes + wave * (kStageBytes / NW);
             __builtin_amdgcn_s_barrier();  // every wave is done reading that slot
             asm volatile("" ::: "memory");
+            // (LDS traffic of this block goes through equss::lds_load_b128 / lds_store_b64: emitted by the compiler,
+            // the first of them would carry s_waitcnt vmcnt(0) and drain the S - 1 ring stages in flight)
+            equss::lds_u32x4 b4u[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b4u[nt] = equss::lds_load_b128(bias_s + n0 + wn * TN + nt * 16 + fq * 4);
+            equss::lds_wait(b4u);
+            f32x4 b4[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b4[nt] = __builtin_bit_cast(f32x4, b4u[nt]);
 #pragma unroll
             for (int pass = 0; pass < TM / RP; ++pass) {
 #pragma unroll
@@ -403,9 +416,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                     const int mt = pass * (RP / 16) + ml;
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + n0 + wn * TN + nt * 16 + fq * 4);
                         f32x4 v = acc[nt][mt];
-                        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+                        v.x += b4[nt].x; v.y += b4[nt].y; v.z += b4[nt].z; v.w += b4[nt].w;
                         if constexpr (EPI == EQUSS_EPI_GELU_BF16) {
                             const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
                             const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
@@ -414,21 +426,24 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                         if constexpr (EPI == EQUSS_EPI_RELU_BF16) {
                             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                         }
-                        uint2 pk;
-                        pk.x = equss::pack_bf16(v.x, v.y);
-                        pk.y = equss::pack_bf16(v.z, v.w);
-                        *reinterpret_cast<uint2*>(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2) = pk;
+                        equss::lds_store_b64(stg + (ml * 16 + fr) * ROWSTRIDE + (nt * 16 + fq * 4) * 2, equss::pack_bf16(v.x, v.y),
+                                             equss::pack_bf16(v.z, v.w));
                     }
                 }
-                asm volatile("" ::: "memory");  // same-wave LDS accesses execute in order
+                equss::lds_u32x4 d[PER_LANE];   // same-wave LDS accesses execute in order
+#pragma unroll
+                for (int j = 0; j < PER_LANE; ++j) {
+                    const int idx = j * 64 + lane;
+                    d[j] = equss::lds_load_b128(stg + (idx / OCH) * ROWSTRIDE + (idx % OCH) * 16);
+                }
+                equss::lds_wait(d);
 #pragma unroll
                 for (int j = 0; j < PER_LANE; ++j) {
                     const int idx = j * 64 + lane;
                     const int row = idx / OCH, ch = idx % OCH;
-                    const uint4 d = *reinterpret_cast<const uint4*>(stg + row * ROWSTRIDE + ch * 16);
                     const int m = m0 + wm * TM + pass * RP + row;
                     if (full || m < g.M)
-                        *reinterpret_cast<uint4*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n0 + wn * TN + ch * 8) = d;
+                        *reinterpret_cast<equss::lds_u32x4*>(reinterpret_cast<u16*>(g.out) + (size_t)m * g.ldo + n0 + wn * TN + ch * 8) = d[j];
                 }
                 asm volatile("" ::: "memory");
             }
