@@ -313,14 +313,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
             float s1[MT], s2[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int m = m0 + wm * TM + mt * 16 + fr;
-                const size_t mo = out_row(m);
                 s1[mt] = 0.f; s2[mt] = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int n = wn * TN + nt * 16 + fq * 4;
                     const f32x4 v = acc[nt][mt];
-                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + mo * g.ldx + n) = v;
                     // (explicit fma placement: layernorm_rowtile_kernel in vit_ops.hip repeats these sums
                     // in the same order so that both routes give the same bits)
                     s1[mt] += (v.x + v.y) + (v.z + v.w);
@@ -370,12 +366,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
                     asm volatile("" ::: "memory");
                 }
             }
+            // x goes back last: the first LDS load the compiler emits after a global_load_lds carries s_waitcnt vmcnt(0),
+            // which would otherwise sit out the round trip of these stores
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m0 + wm * TM + mt * 16 + fr;
+                const size_t mo = out_row(m);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    if (m < g.M) *reinterpret_cast<f32x4*>(g.x + mo * g.ldx + wn * TN + nt * 16 + fq * 4) = acc[nt][mt];
+            }
         } else if constexpr (EPI == EQUSS_EPI_F32 || EPI == EQUSS_EPI_RESID_F32) {
             // lane owns out[m][n .. n+3] as one 16-byte store (EPI_RESID_F32: bias and the old value are already in)
+            // (bias through equss::lds_load_b128: an LDS load emitted by the compiler would wait for the ring stages in flight)
+            equss::lds_u32x4 b4u[NT];
+            if constexpr (EPI == EQUSS_EPI_F32) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) b4u[nt] = equss::lds_load_b128(bias_s + n0 + wn * TN + nt * 16 + fq * 4);
+                equss::lds_wait(b4u);
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = n0 + wn * TN + nt * 16 + fq * 4;
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_s + n);
+                f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+                if constexpr (EPI == EQUSS_EPI_F32) b4 = __builtin_bit_cast(f32x4, b4u[nt]);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int m = m0 + wm * TM + mt * 16 + fr;
