@@ -263,6 +263,10 @@ bool gemm8_supports(int N, int K, int epilogue);
 int gemm8_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
                int M, int N, int K, int epilogue, hipStream_t s);
 
+bool gemm_ws_supports(int M, int N, int K, int epilogue);
+int gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int M, int N,
+                 int K, int epilogue, hipStream_t s);
+
 int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
               int M, int N, int K, int epilogue, hipStream_t s) {
     if (!A || !W || !out) return fail(EQUSS_E_NULL, "gemm_bf16: null pointer argument");
@@ -274,7 +278,10 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
         return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
     // (the in-place residual update keeps the small tiles for short M: that is what the trailing-row
     // routes of the fused kernels want)
-    if (g_variant == 3 && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
+    // long M, N a multiple of 384, bf16 output: the producer / consumer kernel (developer variant 4 keeps it off)
+    if (g_variant == 3 && gemm_ws_supports(M, N, K, epilogue))
+        return gemm_ws_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
+    if ((g_variant == 3 || g_variant == 4) && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
         return gemm8_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
     GemmArgs g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;

@@ -314,3 +314,33 @@ def test_residual_gemm_large_tile_route_equals_small_tile_route(shape, native, d
     assert torch.equal(big, small)
     ref = x0.double() + a.double() @ w.double().t() + bias.double()
     assert float((big.double() - ref).abs().max()) < 5e-4
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(16384 + 57, 1152, 384), (20000, 384, 768), (16384, 768, 64)])
+def test_producer_consumer_gemm_equals_the_one_role_kernels(epi, shape, native, dev):
+    """Long M, N a multiple of 384, bf16 output: the producer / consumer kernel (four request-only waves feed
+    eight MFMA waves) applies the same fp32 operations in the same order as the large-tile and the 128 x 128
+    kernels: equal bits, ragged last row tile and single-K-step-pair shapes included."""
+    import ctypes
+    m, n, k = shape
+    g = _rng(7 * m + n + epi)
+    a = _bf(torch.from_numpy(g.standard_normal((m, k)).astype(np.float32))).to(dev)
+    w = _bf(torch.from_numpy((g.standard_normal((n, k)) / math.sqrt(k)).astype(np.float32))).to(dev)
+    bias = torch.from_numpy(g.standard_normal(n).astype(np.float32)).to(dev)
+    lib = native.load_library()
+    guard = torch.full((m + 8, n), 7.0, dtype=torch.bfloat16, device=dev)      # rows past M must stay untouched
+    ws = native.gemm_bf16(a, w, bias, epi, out=guard[:m])
+    outs = []
+    for variant in (4, 0):
+        lib.equss_dev_gemm_variant(ctypes.c_int(variant))
+        try:
+            outs.append(native.gemm_bf16(a, w, bias, epi))
+        finally:
+            lib.equss_dev_gemm_variant(ctypes.c_int(3))
+    torch.cuda.synchronize()
+    assert torch.equal(ws, outs[0]) and torch.equal(ws, outs[1])
+    assert bool((guard[m:] == 7.0).all())
+    ref = a.double() @ w.double().t() + bias.double()
+    ref = F.gelu(ref) if epi == 1 else F.relu(ref) if epi == 2 else ref
+    assert float((ws.double() - ref).abs().max()) < 0.05

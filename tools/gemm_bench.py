@@ -5,6 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("expand-and-quantize-for-unsupervised-semantic-segmentation_amd")
 nat = pkg.native
+if os.environ.get("EQUSS_LIB"):      # A/B against another build of the library
+    nat.LIB_PATH = os.environ["EQUSS_LIB"]
 lib = nat.load_library()
 dev = torch.device("cuda", 0)
 M = 64 * 1601

@@ -19,7 +19,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds) {
 // MODE 3: as 1, half of the pieces from a tile of the CU's own (96 KiB each, 24 MiB in all)
 // MODE 4: as 3, the shared half walks a 2.25 MiB weight matrix (12 chunks of 128 rows x 768 B x 2 matrices)
 // MODE 5: as 4 with 128-B pieces for both halves
-template <int MODE, int INFLIGHT>
+template <int MODE, int INFLIGHT, int SPREAD>
 __global__ __launch_bounds__(512, 2) void k(const char* shared, const char* own, int steps, float* out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int PW = 4, NM = 24, NR = 18;
@@ -30,9 +30,8 @@ __global__ __launch_bounds__(512, 2) void k(const char* shared, const char* own,
     for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     int issued = 0, ibuf = 0;
     const char* mine = own + (size_t)blockIdx.x * 98304;
-    auto issue = [&]() {
-#pragma unroll
-        for (int p = 0; p < PW; ++p) {
+    auto issue_piece = [&](int p) {
+        {
             const int piece = p * 8 + wave;     // 32 pieces per stage
             const char* src;
             if (MODE == 0) {
@@ -53,8 +52,15 @@ __global__ __launch_bounds__(512, 2) void k(const char* shared, const char* own,
             }
             glds16(src, smem + ibuf * kStage + piece * 1024);
         }
+    };
+    auto issue_done = [&]() {
         ++issued;
         ibuf = ibuf + 1 == S ? 0 : ibuf + 1;
+    };
+    auto issue = [&]() {
+#pragma unroll
+        for (int p = 0; p < PW; ++p) issue_piece(p);
+        issue_done();
     };
 #pragma unroll
     for (int d = 0; d < INFLIGHT; ++d) issue();
@@ -64,15 +70,18 @@ __global__ __launch_bounds__(512, 2) void k(const char* shared, const char* own,
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        issue();
+        if (!SPREAD) issue();
         const char* base = smem + cbuf * kStage;
         cbuf = cbuf + 1 == S ? 0 : cbuf + 1;
         bf16x8 f[NR];
 #pragma unroll
         for (int i = 0; i < NR; ++i) f[i] = *reinterpret_cast<const bf16x8*>(base + ((i * 1024 + lane * 16 + wave * 2048) % kStage));
 #pragma unroll
-        for (int m = 0; m < NM; ++m)
+        for (int m = 0; m < NM; ++m) {
+            if (SPREAD && m % (NM / PW) == 0) { issue_piece(m / (NM / PW)); __builtin_amdgcn_sched_barrier(0); }
             acc[m & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(f[m % NR], f[(m + 1) % NR], acc[m & 7], 0, 0, 0);
+        }
+        if (SPREAD) issue_done();
         asm volatile("" ::: "memory");
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -82,20 +91,20 @@ __global__ __launch_bounds__(512, 2) void k(const char* shared, const char* own,
     if (s == 123.456f) out[threadIdx.x] = s;
 }
 
-template <int MODE, int INFLIGHT>
+template <int MODE, int INFLIGHT, int SPREAD = 0>
 void run(const char* shared, const char* own, float* out, const char* what) {
     const int steps = 4000;
     const int lds = (INFLIGHT + 1) * 32 * 1024;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE, INFLIGHT>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((k<MODE, INFLIGHT>), dim3(256), dim3(512), lds, 0, shared, own, 100, out);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k<MODE, INFLIGHT, SPREAD>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((k<MODE, INFLIGHT, SPREAD>), dim3(256), dim3(512), lds, 0, shared, own, 100, out);
     hipDeviceSynchronize();
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<MODE, INFLIGHT>), dim3(256), dim3(512), lds, 0, shared, own, steps, out);
+    hipLaunchKernelGGL((k<MODE, INFLIGHT, SPREAD>), dim3(256), dim3(512), lds, 0, shared, own, steps, out);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double ns = ms * 1e6 / steps;
-    printf("mode %d (%s), %d in flight: %7.1f ns per step (MFMA alone 320 ns), %5.1f GB/s per CU\n", MODE, what, INFLIGHT, ns, 32768.0 / ns);
+    printf("%smode %d (%s), %d in flight: %7.1f ns per step (MFMA alone 320 ns), %5.1f GB/s per CU\n", SPREAD ? "spread issue, " : "", MODE, what, INFLIGHT, ns, 32768.0 / ns);
 }
 
 int main(int argc, char**) {
@@ -121,5 +130,10 @@ int main(int argc, char**) {
     run<3, 2>(shared, own, out, "64-B pieces, half from the CU's own tile");
     run<4, 2>(shared, own, out, "64-B pieces, own tile + 2.25 MiB of weights");
     run<5, 2>(shared, own, out, "128-B pieces, own tile + 2.25 MiB of weights");
+    run<0, 1, 1>(shared, own, out, "1-KiB contiguous pieces, shared");
+    run<0, 2, 1>(shared, own, out, "1-KiB contiguous pieces, shared");
+    run<4, 1, 1>(shared, own, out, "64-B pieces, own tile + 2.25 MiB of weights");
+    run<4, 2, 1>(shared, own, out, "64-B pieces, own tile + 2.25 MiB of weights");
+    run<5, 2, 1>(shared, own, out, "128-B pieces, own tile + 2.25 MiB of weights");
     return 0;
 }
