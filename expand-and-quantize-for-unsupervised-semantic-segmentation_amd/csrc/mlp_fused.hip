@@ -549,6 +549,9 @@ extern "C" int equss_mlp_resid_ln_bf16(const void* a, int64_t lda, const void* w
     if (M <= 0) return equss::fail(EQUSS_E_SHAPE, "mlp_resid_ln: M=%d must be positive", M);
     if (!equss::mlp_fused_supports(C_, hidden))
         return equss::fail(EQUSS_E_UNSUPPORTED, "mlp_resid_ln: C=%d hidden=%d (384 and 1536 only)", C_, hidden);
+    // (row offsets inside a tile are 32-bit byte offsets of buffer instructions)
+    if (lda > (1 << 22) || ldx > (1 << 22) || ld_ln > (1 << 22))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "mlp_resid_ln: leading dimensions above 2^22 elements are not supported");
     if (lda < C_ || ldx < C_ || (ln_out && ld_ln < C_) || (lda % 8) || (ldx % 4) || (ld_ln % 8) || ((uintptr_t)a % 16) ||
         ((uintptr_t)w1 % 16) || ((uintptr_t)w2 % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
         return equss::fail(EQUSS_E_ALIGN, "mlp_resid_ln: operands must be 16-byte aligned with padded leading dimensions");
@@ -567,6 +570,8 @@ extern "C" int equss_block_tail_bf16(const void* att, int64_t ld_att, const void
     if (M <= 0) return equss::fail(EQUSS_E_SHAPE, "block_tail: M=%d must be positive", M);
     if (!equss::mlp_fused_supports(C_, hidden))
         return equss::fail(EQUSS_E_UNSUPPORTED, "block_tail: C=%d hidden=%d (384 and 1536 only)", C_, hidden);
+    if (ld_att > (1 << 22) || ld_mid > (1 << 22) || ldx > (1 << 22) || ld_ln > (1 << 22))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "block_tail: leading dimensions above 2^22 elements are not supported");
     if (ld_att < C_ || ld_mid < C_ || ldx < C_ || (ln_out && ld_ln < C_) || (ld_att % 8) || (ld_mid % 8) || (ldx % 4) ||
         (ld_ln % 8) || ((uintptr_t)att % 16) || ((uintptr_t)wp % 16) || ((uintptr_t)ln_mid % 16) || ((uintptr_t)w1 % 16) ||
         ((uintptr_t)w2 % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
