@@ -77,7 +77,7 @@ __device__ __forceinline__ void wait_younger(int stages, bool stores_younger) {
 }
 
 template <int EPI, int BM, int BN, int WM, int WN, int BK, int S>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args g) {
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN == 4 && BM * BN >= 128 * 384) ? 1 : 2) void gemm8_kernel(const Gemm8Args g) {
     constexpr int NW = WM * WN;                    // waves per workgroup: 8 (one workgroup per CU) or 4 (two)
     constexpr int kThreads = NW * 64;
     static_assert(NW == 8 || NW == 4, "four or eight waves");
@@ -130,7 +130,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
 
     // ---- issue cursor: which (tile, K step) is staged next, and into which ring slot -------------
     const int st_row = lane / CPR, st_phys = lane % CPR;
-    const u16* src[PW];
+    // per-lane source of piece i as a 32-bit element offset from A or W (which of the two is a property of i:
+    // A_PIECES is a multiple of NW): half the registers of 64-bit pointers
+    static_assert(A_PIECES % NW == 0, "a wave's piece i is an activation piece for every wave or for none");
+    uint32_t src[PW];
     int i_tile = slot, i_kt = 0, i_buf = 0, issued = 0;
     auto set_src = [&](int logical) {
         const int m0 = (logical / g.ntn) * BM;
@@ -138,14 +141,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
 #pragma unroll
         for (int i = 0; i < PW; ++i) {
             const int p = i * NW + wave;  // pieces [0, A_PIECES) are activation rows, the rest weight rows
-            const int row = (p < A_PIECES ? p : p - A_PIECES) * RPP + st_row;
+            const int row = (i * NW < A_PIECES ? p : p - A_PIECES) * RPP + st_row;
             const int chunk = (st_phys ^ swz(row)) * 8;
-            if (p < A_PIECES) {
+            if (i * NW < A_PIECES) {
                 int am = m0 + row;
                 if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; outputs are masked
-                src[i] = g.A + (size_t)am * g.lda + chunk;
+                src[i] = (uint32_t)am * (uint32_t)g.lda + chunk;
             } else {
-                src[i] = g.W + (size_t)(n0 + row) * g.ldw + chunk;
+                src[i] = (uint32_t)(n0 + row) * (uint32_t)g.ldw + chunk;
             }
         }
     };
@@ -153,7 +156,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm8_kernel(const Gemm8Args 
         if (issued >= total) return;
         char* base = smem + i_buf * kStageBytes;
 #pragma unroll
-        for (int i = 0; i < PW; ++i) glds16(src[i] + (size_t)i_kt * BK, base + (i * NW + wave) * 1024);
+        for (int i = 0; i < PW; ++i)
+            glds16((i * NW < A_PIECES ? g.A : g.W) + src[i] + (uint32_t)(i_kt * BK), base + (i * NW + wave) * 1024);
         ++issued;
         i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
         if (++i_kt == nk) {
@@ -500,7 +504,7 @@ template <int EPI>
 int launch(Gemm8Args& g, hipStream_t s) {
     if (g_stages == 5 && g.N % 384 == 0) {
         g.ntn = g.N / 384;
-        return launch_inst<EPI, 128, 384, 1, 4, 32, 2>(g, s);
+        return launch_inst<EPI, 128, 384, 1, 4, 32, 4>(g, s);
     }
     if (g_stages == 6 && g.N % 192 == 0) {   // two 4-wave workgroups per CU, 128 x 192 tiles
         g.ntn = g.N / 192;
@@ -561,7 +565,6 @@ int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const
     g.bias = bias; g.out = nullptr; g.ldo = 0; g.M = M; g.N = N; g.K = K; g.ntn = 1;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps;
     g.pos = nullptr; g.group = 1;
-    if (g_stages == 5) return launch_inst<EPI_RESID_LN, 128, 384, 1, 4, 32, 2>(g, s);
     return launch_inst<EPI_RESID_LN, 128, 384, 2, 4, 64, 2>(g, s);
 }
 

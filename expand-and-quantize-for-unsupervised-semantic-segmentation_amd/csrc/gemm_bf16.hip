@@ -281,7 +281,9 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
     // long M, N a multiple of 384, bf16 output: the producer / consumer kernel (developer variant 4 keeps it off)
     if (g_variant == 3 && gemm_ws_supports(M, N, K, epilogue))
         return gemm_ws_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
-    if ((g_variant == 3 || g_variant == 4) && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
+    // (the large-tile kernel addresses its operand pieces with 32-bit element offsets)
+    const bool fits32 = (int64_t)M * lda < (1LL << 32) && (int64_t)N * ldw < (1LL << 32);
+    if ((g_variant == 3 || g_variant == 4) && fits32 && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
         return gemm8_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
     GemmArgs g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;
