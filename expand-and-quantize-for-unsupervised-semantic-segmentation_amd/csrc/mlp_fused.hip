@@ -143,8 +143,12 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
         const int row0 = m0 + 16 * mt;
         int rows = g.M - row0 < BM - 16 * mt ? g.M - row0 : BM - 16 * mt;
         rows = rows < 0 ? 0 : rows;
-        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(const_cast<void*>(p)) + (size_t)row0 * (size_t)ld * elem, 0,
-                                                 rows * (int)ld * elem, 0x00020000);
+        // (every word through readfirstlane: the values are wave-uniform, but left to itself the compiler keeps some of
+        // them in vector registers and wraps every buffer instruction in a loop that reads them back lane by lane)
+        const uint64_t base = reinterpret_cast<uint64_t>(p) + (uint64_t)row0 * (uint64_t)ld * elem;
+        const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane(rows * (int)ld * elem), 0x00020000);
     };
 
     // ---- staging: 1-KiB pieces of 8 rows; piece p = wave + 8 i, so a wave's pieces share the swizzle --
