@@ -113,6 +113,21 @@ __device__ __forceinline__ void lds_wait(lds_u32x4 (&d)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(d[i]));
 }
+// The same load at a 32-bit LDS address plus an immediate byte offset (< 65536), and the counted wait that goes with
+// it: "all but the N youngest LDS operations of this wave have returned" (they return in order), after which d holds data.
+template <int OFF>
+__device__ __forceinline__ lds_u32x4 lds_load_b128_at(uint32_t addr) {
+    lds_u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_tie(lds_u32x4& d) { asm volatile("" : "+v"(d)); }
+template <int N, typename... R>
+__device__ __forceinline__ void lds_wait_for(R&... d) {
+    __builtin_amdgcn_sched_barrier(0);   // (what was written before the wait stays before it: MFMAs would sink below it)
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    (lds_tie(d), ...);
+}
 __device__ __forceinline__ void lds_store_f32x2(void* p, float a, float b) {
     lds_store_b64(p, __builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
 }

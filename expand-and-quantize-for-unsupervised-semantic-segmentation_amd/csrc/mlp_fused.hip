@@ -60,6 +60,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
         (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
 
+// Fragment reads and MFMA groups of the ring steps are scheduled by hand: inline-asm ds_read_b128 in the order of first
+// use, one counted wait per MFMA group (LD / equss::lds_wait_for), each group at raised wave priority.  Left to the
+// compiler the reads were re-ordered and most groups waited for every read of the step; s_setprio makes the SIMD's
+// other wave issue its reads and its LDS-DMA requests into the gaps of the group that is running (-5 % together).
+typedef equss::lds_u32x4 L4;
+template <int OFF> __device__ __forceinline__ L4 LD(uint32_t a) { return equss::lds_load_b128_at<OFF>(a); }
+__device__ __forceinline__ f32x4 MM(const L4& a, const L4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 #ifdef EQUSS_MLP_STAMPS   // developer build (tools/ubench/mlp_stamps.hip): 100 MHz clock at the phase boundaries of every wave of one workgroup
 constexpr int kStampMax = 160;
 __device__ unsigned long long g_mlp_stamps[NW * kStampMax];
@@ -303,18 +313,29 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // partial sums visible; that ring slot no longer read
             asm volatile("" ::: "memory");
+            // scale / shift of the wave's 96 columns and the four partial sums of its rows: one batch of LDS reads, one wait
+            L4 gau[6], beu[6], pru[4][2];
+            {
+                const uint32_t sg = equss::lds_addr(gs) + (wn * 96 + fq_e * 4) * 4, sb = equss::lds_addr(bs) + (wn * 96 + fq_e * 4) * 4;
+                const uint32_t sp = equss::lds_addr(red_s) + (wm * 64 + fr_e) * WN * 8;
+                pru[0][0] = LD<0>(sp); pru[0][1] = LD<16>(sp);
+                gau[0] = LD<0>(sg); gau[1] = LD<64>(sg); gau[2] = LD<128>(sg); gau[3] = LD<192>(sg); gau[4] = LD<256>(sg); gau[5] = LD<320>(sg);
+                beu[0] = LD<0>(sb); beu[1] = LD<64>(sb); beu[2] = LD<128>(sb); beu[3] = LD<192>(sb); beu[4] = LD<256>(sb); beu[5] = LD<320>(sb);
+                pru[1][0] = LD<16 * WN * 8>(sp); pru[1][1] = LD<16 * WN * 8 + 16>(sp);
+                pru[2][0] = LD<32 * WN * 8>(sp); pru[2][1] = LD<32 * WN * 8 + 16>(sp);
+                pru[3][0] = LD<48 * WN * 8>(sp); pru[3][1] = LD<48 * WN * 8 + 16>(sp);
+                equss::lds_wait_for<0>(gau[0], gau[1], gau[2], gau[3], gau[4], gau[5], beu[0], beu[1], beu[2], beu[3], beu[4], beu[5],
+                                       pru[0][0], pru[0][1], pru[1][0], pru[1][1], pru[2][0], pru[2][1], pru[3][0], pru[3][1]);
+            }
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
-                const float2* pr = red_s + (wm * 64 + mt * 16 + fr_e) * WN;
-                const float2 p0 = pr[0], p1 = pr[1], p2 = pr[2], p3 = pr[3];
-                const float mean = ((p0.x + p1.x) + (p2.x + p3.x)) * (1.0f / C);
-                const float ex2 = ((p0.y + p1.y) + (p2.y + p3.y)) * (1.0f / C);
+                const f32x4 q0 = __builtin_bit_cast(f32x4, pru[mt][0]), q1 = __builtin_bit_cast(f32x4, pru[mt][1]);   // (sum, sum of squares) x 2
+                const float mean = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
+                const float ex2 = ((q0.y + q0.w) + (q1.y + q1.w)) * (1.0f / C);
                 const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
 #pragma unroll
                 for (int nt = 0; nt < 6; ++nt) {
-                    const int n = wn * 96 + nt * 16 + fq_e * 4;
-                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + n);
-                    const f32x4 be = *reinterpret_cast<const f32x4*>(bs + n);
+                    const f32x4 ga = __builtin_bit_cast(f32x4, gau[nt]), be = __builtin_bit_cast(f32x4, beu[nt]);
                     const f32x4 v = acc2[nt][mt];
                     const uint32_t lo = equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y));
                     const uint32_t hi = equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w));
@@ -371,16 +392,26 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
 #endif
                     MLP_STAMP();   // residual rows have arrived
                 }
-                bf16x8 af[4], wf[6];
+                {
+                    const uint32_t sa = equss::lds_addr(base) + (wm * 64 + fr) * 64 + g0_off;
+                    const uint32_t sw = equss::lds_addr(base) + 8192 + (wn * 96 + fr) * 64 + g0_off;
+                    L4 a[4], w[6];
+                    a[0] = LD<0>(sa); a[1] = LD<1024>(sa); a[2] = LD<2048>(sa); a[3] = LD<3072>(sa);
+                    w[0] = LD<0>(sw); w[1] = LD<1024>(sw); w[2] = LD<2048>(sw);
+                    w[3] = LD<3072>(sw); w[4] = LD<4096>(sw); w[5] = LD<5120>(sw);
+                    __builtin_amdgcn_s_setprio(1);
+                    equss::lds_wait_for<3>(a[0], a[1], a[2], a[3], w[0], w[1], w[2]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + (wm * 64 + i * 16 + fr) * 64 + g0_off);
+                    for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-                for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + 8192 + (wn * 96 + i * 16 + fr) * 64 + g0_off);
+                        for (int mt = 0; mt < 4; ++mt) acc2[nt][mt] = MM(w[nt], a[mt], acc2[nt][mt]);
+                    equss::lds_wait_for<0>(w[3], w[4], w[5]);
 #pragma unroll
-                for (int nt = 0; nt < 6; ++nt)
+                    for (int nt = 3; nt < 6; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
-                        acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc2[nt][mt], 0, 0, 0);
+                        for (int mt = 0; mt < 4; ++mt) acc2[nt][mt] = MM(w[nt], a[mt], acc2[nt][mt]);
+                    __builtin_amdgcn_s_setprio(0);
+                }
                 asm volatile("" ::: "memory");
             }
             MLP_STAMP();   // projection steps done
@@ -406,20 +437,32 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                 for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int kt = 0; kt < G1S; ++kt) {
                 const char* base = sync_step(kt + 1 < G1S);
-#pragma unroll
-                for (int sub = 0; sub < 3; ++sub) {
-                    bf16x8 af[4], wf[2];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        af[i] = *reinterpret_cast<const bf16x8*>(base + sub * 8192 + (wm * 64 + i * 16 + fr) * 64 + g0_off);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        wf[i] = *reinterpret_cast<const bf16x8*>(base + 24576 + sub * 8192 + (wn * 32 + i * 16 + fr) * 64 + g0_off);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc1[nt][mt], 0, 0, 0);
+                {   // three 32-wide sub-tiles: the reads of sub-tile s + 1 are in flight during the MFMAs of sub-tile s
+                    const uint32_t sa = equss::lds_addr(base) + (wm * 64 + fr) * 64 + g0_off;
+                    const uint32_t sw = equss::lds_addr(base) + 24576 + (wn * 32 + fr) * 64 + g0_off;
+                    L4 f0[6], f1[6], f2[6];   // four row fragments of a, two of W1
+#define EQUSS_G1_LOAD(f, sub)                                                                                      \
+                    f[0] = LD<sub * 8192>(sa); f[1] = LD<sub * 8192 + 1024>(sa); f[2] = LD<sub * 8192 + 2048>(sa); \
+                    f[3] = LD<sub * 8192 + 3072>(sa); f[4] = LD<sub * 8192>(sw); f[5] = LD<sub * 8192 + 1024>(sw);
+#define EQUSS_G1_MMS(f)                                                      \
+                    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)         \
+                        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc1[nt][mt] = MM(f[4 + nt], f[mt], acc1[nt][mt]);
+                    EQUSS_G1_LOAD(f0, 0)
+                    EQUSS_G1_LOAD(f1, 1)
+                    __builtin_amdgcn_s_setprio(1);
+                    equss::lds_wait_for<6>(f0[0], f0[1], f0[2], f0[3], f0[4], f0[5]);
+                    EQUSS_G1_MMS(f0)
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    EQUSS_G1_LOAD(f2, 2)
+                    __builtin_amdgcn_s_setprio(1);
+                    equss::lds_wait_for<6>(f1[0], f1[1], f1[2], f1[3], f1[4], f1[5]);
+                    EQUSS_G1_MMS(f1)
+                    equss::lds_wait_for<0>(f2[0], f2[1], f2[2], f2[3], f2[4], f2[5]);
+                    EQUSS_G1_MMS(f2)
+                    __builtin_amdgcn_s_setprio(0);
+#undef EQUSS_G1_LOAD
+#undef EQUSS_G1_MMS
                 }
                 asm volatile("" ::: "memory");
             }
@@ -464,18 +507,37 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             for (int kt = 0; kt < G2S; ++kt) {
                 const char* base = sync_step(kt + 1 == G2S);
                 const char* hb = hc + kt * 16384;
-#pragma unroll 1
-                for (int ks = 0; ks < 2; ++ks) {   // (not unrolled: both sub-steps' fragments in flight would spill)
-                    bf16x8 hf[4], wf[6];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) hf[i] = *reinterpret_cast<const bf16x8*>(hb + a_row + i * 2048 + (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16));
-#pragma unroll
-                    for (int i = 0; i < 6; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w2_row + i * 2048 + (((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16));
-#pragma unroll
-                    for (int nt = 0; nt < 6; ++nt)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], hf[mt], acc2[nt][mt], 0, 0, 0);
+                {   // two 32-wide sub-steps in four groups of twelve MFMAs; every fragment is requested at least one group
+                    // before its first use, the second sub-step's weight fragments into the registers a group has finished with
+                    const uint32_t sh0 = equss::lds_addr(hb) + a_row + c_off[0], sh1 = equss::lds_addr(hb) + a_row + c_off[1];
+                    const uint32_t sw0 = equss::lds_addr(base) + w2_row + c_off[0], sw1 = equss::lds_addr(base) + w2_row + c_off[1];
+                    L4 h0[4], h1[4], wa[3], wb[3], wc[3], wd[3];
+                    h0[0] = LD<0>(sh0); h0[1] = LD<2048>(sh0); h0[2] = LD<4096>(sh0); h0[3] = LD<6144>(sh0);
+                    wa[0] = LD<0>(sw0); wa[1] = LD<2048>(sw0); wa[2] = LD<4096>(sw0);
+                    wb[0] = LD<6144>(sw0); wb[1] = LD<8192>(sw0); wb[2] = LD<10240>(sw0);
+                    h1[0] = LD<0>(sh1); h1[1] = LD<2048>(sh1); h1[2] = LD<4096>(sh1); h1[3] = LD<6144>(sh1);
+#define EQUSS_G2_MMS(W, H, NT0)                                              \
+                    _Pragma("unroll") for (int nt = 0; nt < 3; ++nt)         \
+                        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) acc2[NT0 + nt][mt] = MM(W[nt], H[mt], acc2[NT0 + nt][mt]);
+                    __builtin_amdgcn_s_setprio(1);
+                    equss::lds_wait_for<7>(h0[0], h0[1], h0[2], h0[3], wa[0], wa[1], wa[2]);
+                    EQUSS_G2_MMS(wa, h0, 0)
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wc[0] = LD<0>(sw1); wc[1] = LD<2048>(sw1); wc[2] = LD<4096>(sw1);
+                    __builtin_amdgcn_s_setprio(1);
+                    equss::lds_wait_for<7>(wb[0], wb[1], wb[2]);
+                    EQUSS_G2_MMS(wb, h0, 3)
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    wd[0] = LD<6144>(sw1); wd[1] = LD<8192>(sw1); wd[2] = LD<10240>(sw1);
+                    __builtin_amdgcn_s_setprio(1);
+                    equss::lds_wait_for<3>(h1[0], h1[1], h1[2], h1[3], wc[0], wc[1], wc[2]);
+                    EQUSS_G2_MMS(wc, h1, 0)
+                    equss::lds_wait_for<0>(wd[0], wd[1], wd[2]);
+                    EQUSS_G2_MMS(wd, h1, 3)
+                    __builtin_amdgcn_s_setprio(0);
+#undef EQUSS_G2_MMS
                 }
                 asm volatile("" ::: "memory");
             }

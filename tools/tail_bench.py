@@ -22,14 +22,19 @@ if os.environ.get("TAIL_CONST"):   # constant operands: the matrix pipe draws le
     for t in (wp, w1, w2, att):
         t.fill_(0.0078125)
     x.fill_(1.0)
+x0 = x.clone()
+out = nat.block_tail_bf16(att, wp, bp, g2, be2, w1, b1, w2, b2, x0, g, be)
+torch.cuda.synchronize()
+import hashlib
+digest = hashlib.sha1(x0.cpu().numpy().tobytes()).hexdigest()[:12]   # equal bits between builds that should agree
 for _ in range(3):
     nat.block_tail_bf16(att, wp, bp, g2, be2, w1, b1, w2, b2, x, g, be)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(10):
+for _ in range(40):
     nat.block_tail_bf16(att, wp, bp, g2, be2, w1, b1, w2, b2, x, g, be)
 e1.record(); torch.cuda.synchronize()
-us = e0.elapsed_time(e1) / 10 * 1e3
+us = e0.elapsed_time(e1) / 40 * 1e3
 flops = rows * (2.0 * c * c + 4.0 * c * hid)
-print(f"block_tail {os.environ.get('EQUSS_LIB', 'default'):40s} rows {rows}: {us:7.1f} us  {flops / us / 1e6:6.1f} TF")
+print(f"block_tail {os.environ.get('EQUSS_LIB', 'default'):40s} rows {rows}: {us:7.1f} us  {flops / us / 1e6:6.1f} TF  x digest {digest}")
