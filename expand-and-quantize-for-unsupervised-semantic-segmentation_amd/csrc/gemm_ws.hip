@@ -32,15 +32,22 @@ struct WsArgs {
     int M, N, K, ntn;
 };
 
-constexpr int BM = 128, BN = 384, BK = 32;
+constexpr int BM = 128, BN = 384;
 constexpr int NC = 8, NP = 4, WN = 4;             // consumer waves (2 x 4), producer waves
 constexpr int kThreads = (NC + NP) * 64;
 constexpr int TM = 64, TN = 96, MT = 4, NT = 6;
-constexpr int ROWB = BK * 2;                      // 64-byte tile rows
-constexpr int kStage = (BM + BN) * ROWB;          // 32 KiB
-constexpr int PIECES = kStage / 1024;             // 32 pieces of 16 rows
-constexpr int PW = PIECES / NP;                   // 8 per producer wave
-constexpr int A_PIECES = BM / 16;
+// K step BK = 32: 64-byte tile rows, 1-KiB pieces of 16 rows, four ring slots of 32 KiB.
+// K step BK = 64: 128-byte tile rows, pieces of 8 rows, two slots of 64 KiB.  A request for a 64-byte row piece costs the
+// address path what one for a 128-byte piece costs (tools/ubench/ring_ws.hip: 66 against 96-115 GB/s per CU with idle
+// consumers), and the wide step has half the barriers.
+template <int BK> struct Geo {
+    static constexpr int ROWB = BK * 2;                      // bytes per tile row
+    static constexpr int RPP = 1024 / ROWB;                  // rows per 1-KiB piece
+    static constexpr int kStage = (BM + BN) * ROWB;
+    static constexpr int PIECES = kStage / 1024;
+    static constexpr int PW = PIECES / NP;                   // pieces per producer wave
+    static constexpr int A_PIECES = BM / RPP;
+};
 constexpr int ROWSTRIDE = TN * 2 + 16, RP = 16, OCH = TN * 2 / 16, PER_LANE = RP * OCH / 64;   // epilogue re-shaping
 constexpr int kStg = RP * ROWSTRIDE;              // staging bytes per consumer wave
 
@@ -49,14 +56,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
         (const void __attribute__((address_space(1)))*)gsrc,
         (void __attribute__((address_space(3)))*)lds_wave_base, 16, 0, 0);
 }
-__device__ __forceinline__ int swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // see gemm8_bf16.hip
+// 16-byte chunk swizzle of a tile row (see gemm8_bf16.hip): 4 chunks per 64-byte row, 8 per 128-byte row
+template <int BK> __device__ __forceinline__ int swz(int row) {
+    if constexpr (BK == 32) return (0x78 >> (2 * ((row >> 2) & 3))) & 3;
+    else return (row >> 1) & 7;
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int EPI, int S>
+template <int EPI, int S, int BK>
 __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
-    static_assert(S >= 3 && S <= 5, "ring depth");
+    using G = Geo<BK>;
+    constexpr int ROWB = G::ROWB, RPP = G::RPP, kStage = G::kStage, PW = G::PW, A_PIECES = G::A_PIECES;
+    constexpr int CPR = ROWB / 16;                    // chunks per row = lanes per row of a piece
+    static_assert(S >= 2 && S <= 5, "ring depth");
     static_assert((S - 2) * PW <= 63, "vmcnt range");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -86,7 +100,7 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
     if (wave >= NC) {
         // ================= producers =================
         const int pw = wave - NC;
-        const int st_row = lane >> 2, st_phys = lane & 3;
+        const int st_row = lane / CPR, st_phys = lane % CPR;
         const u16* src[PW];
         int i_tile = 0, i_kt = 0, i_buf = 0, issued = 0;
         auto set_src = [&](int logical) {
@@ -95,8 +109,8 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
 #pragma unroll
             for (int i = 0; i < PW; ++i) {
                 const int p = i * NP + pw;   // pieces [0, A_PIECES) are activation rows, the rest weight rows
-                const int row = (p < A_PIECES ? p : p - A_PIECES) * 16 + st_row;
-                const int chunk = (st_phys ^ swz(row)) * 8;
+                const int row = (p < A_PIECES ? p : p - A_PIECES) * RPP + st_row;
+                const int chunk = (st_phys ^ swz<BK>(row)) * 8;
                 if (p < A_PIECES) {
                     int am = m0 + row;
                     if (am > g.M - 1) am = g.M - 1;  // tail rows re-read the last row; outputs are masked
@@ -122,10 +136,13 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
         // "stage j has landed": at most the pieces of the stages requested after it are outstanding
         auto wait_stage = [&](int j) {
             const int younger = issued - 1 - j;
-            if (younger >= S - 2) wait_vm<(S - 2) * PW>();
-            else if (younger == 2) wait_vm<2 * PW>();
-            else if (younger == 1) wait_vm<PW>();
-            else wait_vm<0>();
+            if constexpr (S == 2) wait_vm<0>();
+            else {
+                if (younger >= S - 2) wait_vm<(S - 2) * PW>();
+                else if (younger == 2) wait_vm<(S > 3 ? 2 : 1) * PW>();
+                else if (younger == 1) wait_vm<PW>();
+                else wait_vm<0>();
+            }
         };
         set_src(tile_of(0));
 #pragma unroll
@@ -144,9 +161,12 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
     // ================= consumers =================
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
-    const int c_off = (fq ^ swz(fr)) * 16;
-    const int a_base = (wm * TM + fr) * ROWB + c_off;
-    const int w_base = BM * ROWB + (wn * TN + fr) * ROWB + c_off;
+    // fragment read: 16-byte chunk fq (+ 4 per further 32 of K) of row fr (+ 16 per further fragment: same swizzle)
+    int c_off[BK / 32];
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) c_off[ks] = ((4 * ks + fq) ^ swz<BK>(fr)) * 16;
+    const int a_base = (wm * TM + fr) * ROWB;
+    const int w_base = BM * ROWB + (wn * TN + fr) * ROWB;
     char* stg = smem + S * kStage + wave * kStg;
     int c_buf = 0;
     __builtin_amdgcn_s_barrier();                           // B_0
@@ -161,23 +181,26 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
             for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kt = 0; kt < nk; ++kt) {
             const char* base = smem + c_buf * kStage;
-            bf16x8 af[MT], wf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_base + i * 16 * ROWB);
+            for (int ks = 0; ks < BK / 32; ++ks) {
+                bf16x8 af[MT], wf[NT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w_base + i * 16 * ROWB);
+                for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const bf16x8*>(base + a_base + c_off[ks] + i * 16 * ROWB);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(base + w_base + c_off[ks] + i * 16 * ROWB);
 #ifndef EQUSS_ABL_WSNOMFMA
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt], af[mt], acc[nt][mt], 0, 0, 0);
 #else
 #pragma unroll
-            for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(af[i]));
+                for (int i = 0; i < MT; ++i) asm volatile("" ::"v"(af[i]));
 #pragma unroll
-            for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(wf[i]));
+                for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(wf[i]));
 #endif
+            }
             c_buf = c_buf + 1 == S ? 0 : c_buf + 1;
             if (kt + 1 < nk) {
                 asm volatile("" ::: "memory");
@@ -246,27 +269,35 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_ws_kernel(const WsArgs g) {
     }
 }
 
-template <int EPI>
-int launch(const WsArgs& g, hipStream_t s) {
-    constexpr int S = 4;
+int g_ws_bk = 64;   // developer knob: K step of the ring (32 or 64)
+
+template <int EPI, int S, int BK>
+int launch_geo(const WsArgs& g, hipStream_t s) {
+    constexpr int kStage = Geo<BK>::kStage;
     const int ntiles = ((g.M + BM - 1) / BM) * g.ntn;
     const int grid = ntiles < 256 ? ntiles : 256;
     if (g.N > 1152) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm_ws: N=%d exceeds the bias staging area", g.N);
     constexpr int lds = S * kStage + NC * kStg + 1152 * 4;
     static_assert(lds <= 163840, "LDS budget");
-    auto kern = gemm_ws_kernel<EPI, S>;
+    auto kern = gemm_ws_kernel<EPI, S, BK>;
     if (!equss::lds_opt_in(reinterpret_cast<const void*>(kern), lds))
         return equss::fail(EQUSS_E_UNSUPPORTED, "gemm_ws: cannot reserve %d bytes of LDS", lds);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, s, g);
     return equss::check_launch("gemm_ws_kernel");
 }
+template <int EPI>
+int launch(const WsArgs& g, hipStream_t s) {
+    return g_ws_bk == 64 && g.K % 64 == 0 ? launch_geo<EPI, 2, 64>(g, s) : launch_geo<EPI, 4, 32>(g, s);
+}
 
 }  // namespace
+
+extern "C" void equss_dev_ws_bk(int bk) { g_ws_bk = bk == 32 ? 32 : 64; }  // tuning knob, not part of the ABI
 
 namespace equss {
 
 bool gemm_ws_supports(int M, int N, int K, int epilogue) {
-    return N % BN == 0 && N <= 1152 && K % BK == 0 && M >= 16384 &&
+    return N % BN == 0 && N <= 1152 && K % 32 == 0 && M >= 16384 &&
            (epilogue == EQUSS_EPI_BF16 || epilogue == EQUSS_EPI_GELU_BF16 || epilogue == EQUSS_EPI_RELU_BF16);
 }
 

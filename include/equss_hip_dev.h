@@ -19,6 +19,8 @@ void equss_dev_pq_mode(int mode);
 void equss_dev_gemm_variant(int variant);
 /* large-tile GEMM ring: bits 0..2 = stages (2 default, 3, 4), bit 3 = prefer the 256x256 tile. */
 void equss_dev_gemm_stages(int stages);
+/* K step of the producer / consumer GEMM's ring: 64 (two 64-KiB slots, default) or 32 (four 32-KiB slots). */
+void equss_dev_ws_bk(int bk);
 /* CUs a large-tile GEMM launch may occupy (1..256, default 256). */
 void equss_dev_gemm_cu_share(int cus);
 /* waves per attention workgroup: 0 (default) = 4, 8 = the 8-wave variant. */

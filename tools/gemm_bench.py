@@ -22,7 +22,10 @@ for name, m, n, k, epi in SHAPES:
     out = torch.zeros(m, n, device=dev, dtype=torch.float32 if epi in (3, 4) else torch.bfloat16)
     ref = None
     for v in variants:
-        if v in STAGES:
+        lib.equss_dev_ws_bk(ctypes.c_int(32 if v == 332 else 64))   # 332: the producer / consumer kernel with 32-wide K steps
+        if v == 332:
+            lib.equss_dev_gemm_variant(ctypes.c_int(3))
+        elif v in STAGES:
             lib.equss_dev_gemm_variant(ctypes.c_int(3))
             lib.equss_dev_gemm_stages(ctypes.c_int(STAGES[v]))
         else:

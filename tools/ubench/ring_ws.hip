@@ -139,5 +139,10 @@ int main() {
     run<32, 4, 24, 10, 512>(shared, own, out);
     run<32, 4, 24, 10, 1024>(shared, own, out);
     run<32, 4, 0, 0, 1024>(shared, own, out);
+    run<32, 4, 0, 0, 0>(shared, own, out);      // which of the two slows the requests down: the 64-B pieces ...
+    run<32, 4, 0, 0, 1>(shared, own, out);
+    run<32, 4, 0, 10, 1024>(shared, own, out);  // ... or the consumers' LDS reads
+    run<32, 4, 0, 10, 1>(shared, own, out);
+    run<32, 4, 24, 0, 1024>(shared, own, out);  // ... or their MFMAs
     return 0;
 }
