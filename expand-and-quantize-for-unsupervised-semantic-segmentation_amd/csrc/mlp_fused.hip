@@ -32,6 +32,9 @@ struct MlpArgs {
     u16* ln; int64_t ld_ln;           // LayerNorm(x) for the next consumer (may be null)
     float eps;
     int M;
+    // TILED variant: the projection and fc1 weights in ring-stage order (pack_tail_weights below), so that every LDS-DMA
+    // request moves 1 KiB of consecutive memory
+    const u16* Wpt; const u16* W1t;
 };
 
 constexpr int C = 384, HID = 1536, BM = 128, HC = 128, BK = 64;
@@ -78,8 +81,15 @@ __device__ unsigned long long g_mlp_stamps[NW * kStampMax];
 #define MLP_STAMP() do { } while (0)
 #endif
 
-template <bool PROJ>
+// TILED (with PROJ): the 32-wide K slices of Wp and W1 come from stage images of those matrices, and a full tile's
+// LayerNorm2 rows are written to g.A in the image order of its G1 stages too (g.A is scratch of this kernel: rows
+// [m0, m0 + 128) x 384 are the tile's own 96 KiB, whatever their order inside), so all of a G1 stage and three quarters of a
+// projection stage arrive as 1-KiB runs of consecutive memory.  A request for a 64-byte row piece costs the address path what
+// one for 128 consecutive bytes costs: 66 against 115 GB/s per CU (tools/ubench/ring_ws.hip), and these stages are what the
+// ring steps wait for.  Image order of a 32-wide slice: [16-row piece][row in piece][16-byte chunk, XORed as in LDS].
+template <bool PROJ, bool TILED>
 __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
+    static_assert(PROJ || !TILED, "the stage-image operands belong to the block-tail variant");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -140,6 +150,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     // the stores just issued, so the epilogues stored one row piece per memory round trip.)
     // The lane offsets are recomputed where they are used, from a lane number the compiler cannot see through
     // (a dozen integer instructions per tile): kept across the kernel they would not fit beside the accumulators.
+    auto swz4t = [](int q) { return (0x78 >> (2 * q)) & 3; };   // (= swz4 below)
     auto opaque_lane = [&]() { int l = lane; asm volatile("" : "+v"(l)); return l; };
     auto x_lane_of = [&](int l) { return (uint32_t)((wm * 64 + (l & 15)) * (int)g.ldx + wn * 96 + (l >> 4) * 4) * 4u; };   // + nt * 64 bytes
     constexpr int OCH = 12, PER_LANE = 16 * OCH / 64;     // 16-byte chunks per output row piece, stores per lane
@@ -148,6 +159,12 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     auto out_lane_of = [&](int l, int j, int64_t ld) {
         const int idx = j * 64 + l;
         return (uint32_t)((wm * 64 + idx / OCH) * (int)ld + wn * 96 + (idx % OCH) * 8) * 2u;
+    };
+    // LayerNorm2 rows in stage-image order: byte offset of the lane's piece j in the tile's 96 KiB, + 1024 per 16-row group:
+    // columns wn * 96 .. + 96 are G1 step wn, 32-wide slice (idx % OCH) / 4, 16-byte chunk (idx % OCH) % 4 of row idx / OCH
+    auto out_tiled_of = [&](int l, int j) {
+        const int idx = j * 64 + l, r16 = idx / OCH, c12 = idx % OCH;
+        return (uint32_t)((wn * 3 + c12 / 4) * 8192 + wm * 4096 + (r16 * 4 + ((c12 & 3) ^ swz4t(r16 >> 2))) * 16);
     };
     auto rows_rsrc = [&](const void* p, int64_t ld, int elem, int m0, int mt) {
         const int row0 = m0 + 16 * mt;
@@ -178,8 +195,15 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
     const u16* a0_src = nullptr;
     int i_tile = slot, i_p = 0, i_c = 0, i_j = 0, i_buf = 0, issued = 0;
     bool hold_ok = false;   // PROJ: the tile's LayerNorm2 rows are in memory, the first G1 stage may be requested
+    bool i_tiled = false;   // TILED: the tile being requested is full, its LayerNorm2 rows are in stage-image order
+    const int img_lane = wave * 512 + lane * 8;   // element offset of this lane's 16 bytes in an 8-KiB slice image (piece = wave)
     auto set_a = [&](int logical) {
         const int m0 = logical * BM;
+        if (TILED) {
+            i_tiled = m0 + BM <= g.M;
+            if (i_tiled) a_src = g.A + (size_t)m0 * C + img_lane;
+        }
+        if (!(TILED && i_tiled))
         {
             int am = m0 + g0_row;
             if (am > g.M - 1) am = g.M - 1;   // tail rows re-read the last row; outputs are masked
@@ -197,8 +221,10 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
         if (PROJ && i_p < G0S) {
             glds16(a0_src + i_p * 32, base + wave * 1024);
 #pragma unroll
-            for (int i = 0; i < 3; ++i)
-                glds16(g.Wp + (size_t)(g0_row + 128 * i) * C + g0_chunk + i_p * 32, base + 8192 + (wave + 8 * i) * 1024);
+            for (int i = 0; i < 3; ++i) {
+                if (TILED) glds16(g.Wpt + i_p * 12288 + i * 4096 + img_lane, base + 8192 + (wave + 8 * i) * 1024);
+                else glds16(g.Wp + (size_t)(g0_row + 128 * i) * C + g0_chunk + i_p * 32, base + 8192 + (wave + 8 * i) * 1024);
+            }
             ++i_p;
             ++issued;
             i_buf = i_buf + 1 == S ? 0 : i_buf + 1;
@@ -209,11 +235,14 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             hold_ok = false;
         }
         if (i_j < G1S) {
-            const u16* w1 = g.W1 + (size_t)(i_c * HC + g0_row) * C + g0_chunk + i_j * G1W;
+            const u16* w1 = TILED ? g.W1t + (i_c * G1S + i_j) * 12288 + img_lane
+                                  : g.W1 + (size_t)(i_c * HC + g0_row) * C + g0_chunk + i_j * G1W;
+            const u16* as = TILED && i_tiled ? a_src + i_j * 12288 : a_src + i_j * G1W;
+            const int sub_step = TILED && i_tiled ? 4096 : 32;   // elements from one 32-wide slice to the next
 #pragma unroll
             for (int sub = 0; sub < 3; ++sub) {
-                glds16(a_src + i_j * G1W + sub * 32, base + sub * 8192 + wave * 1024);
-                glds16(w1 + sub * 32, base + 24576 + sub * 8192 + wave * 1024);
+                glds16(as + sub * sub_step, base + sub * 8192 + wave * 1024);
+                glds16(w1 + sub * (TILED ? 4096 : 32), base + 24576 + sub * 8192 + wave * 1024);
             }
         } else {
             const u16* w2 = g.W2 + w2_off + i_c * HC + (i_j - G1S) * BK;
@@ -272,7 +301,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
         // red_s between the four waves that share a row; the bf16 rows are re-shaped through the wave's part of
         // the ring slot consumed last (8-byte fragments in, 16-byte row pieces out).  Every address below derives
         // from opaque_lane(), so nothing of it stays in registers between tiles.
-        auto rows_out = [&](bool with_x, bool with_ln, const float* gs, const float* bs, const void* dst, int64_t ld_dst) {
+        auto rows_out = [&](bool with_x, bool with_ln, const float* gs, const float* bs, const void* dst, int64_t ld_dst, bool tiled) {
             constexpr int ROWSTRIDE = 96 * 2 + 16;
             const int ol = opaque_lane();
             const int fr_e = ol & 15, fq_e = ol >> 4;
@@ -342,12 +371,14 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
                     equss::lds_store_b64(stg + fr_e * ROWSTRIDE + (nt * 16 + fq_e * 4) * 2, lo, hi);
                 }
                 asm volatile("" ::: "memory");
-                const __amdgpu_buffer_rsrc_t out_rs = rows_rsrc(dst, ld_dst, 2, m0, mt);
+                // (tiled: one resource over the tile's 96 KiB, the 16-row group as the scalar offset)
+                const __amdgpu_buffer_rsrc_t out_rs = TILED && tiled ? rows_rsrc(dst, C, 2, m0, 0) : rows_rsrc(dst, ld_dst, 2, m0, mt);
 #pragma unroll
                 for (int j = 0; j < PER_LANE; ++j) {
                     const u32x4 d = *reinterpret_cast<const u32x4*>(stg + stg_off_of(ol, j));
 #ifndef EQUSS_ABL_NOSTORE
-                    __builtin_amdgcn_raw_buffer_store_b128(d, out_rs, out_lane_of(ol, j, ld_dst), 0, 0);
+                    if (TILED && tiled) __builtin_amdgcn_raw_buffer_store_b128(d, out_rs, out_tiled_of(ol, j), mt * 1024, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(d, out_rs, out_lane_of(ol, j, ld_dst), 0, 0);
 #else
                     asm volatile("" :: "v"(d));
 #endif
@@ -417,7 +448,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
             MLP_STAMP();   // projection steps done
             // ---- LayerNorm2 of the updated rows -> memory (g.A), from where the G1 steps stage it ------------
             {
-                rows_out(false, true, gamma2_s, beta2_s, g.A, g.lda);
+                rows_out(false, true, gamma2_s, beta2_s, g.A, g.lda, full);
                 // Workgroup-scope release / acquire: the stores have completed, every wave of the workgroup
                 // (one CU, one vector L1) is past the barrier, then the rows are read back by LDS-DMA.
                 asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -546,7 +577,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
         // ---- epilogue: x back, LayerNorm statistics, normalised rows as bf16 (as gemm8's residual epilogue) --
         // (the slot consumed by the last step is free: the other one is receiving the next tile's first stage;
         // red_s is rewritten by the next tile only after ~100 barriers)
-        rows_out(true, g.ln != nullptr, gamma_s, beta_s, g.ln, g.ld_ln);
+        rows_out(true, g.ln != nullptr, gamma_s, beta_s, g.ln, g.ld_ln, false);
         MLP_STAMP();   // epilogue issued
     }
 #ifdef EQUSS_MLP_STAMPS
@@ -556,20 +587,61 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
 #endif
 }
 
+// Stage images of a block's projection and fc1 weights (see mlp_kernel<true, true>): one thread per 16 bytes.
+//   wpt: [step 0..11][piece 0..23][64 lanes][8]   <- Wp rows piece*16 + lane/4, columns step*32 + chunk*8
+//   w1t: [chunk 0..11][step 0..3][slice 0..2][piece 0..7][64 lanes][8]  <- W1 rows chunk*128 + piece*16 + lane/4,
+//        columns step*96 + slice*32 + chunk*8;       chunk = (lane & 3) ^ swz4(lane >> 4), the LDS chunk swizzle
+constexpr int kWptUnits = G0S * 24 * 64, kW1tUnits = NCH * G1S * 3 * 8 * 64;
+struct PackArgs { const u16* wp[16]; const u16* w1[16]; u16* out; };
+__global__ __launch_bounds__(256) void pack_tail_weights_kernel(const PackArgs a) {
+    const int blk = blockIdx.y;
+    const int u = blockIdx.x * 256 + threadIdx.x;
+    if (u >= kWptUnits + kW1tUnits) return;
+    const int l = u & 63, row16 = l >> 2, chunk = ((l & 3) ^ ((0x78 >> (2 * (l >> 4))) & 3)) * 8;
+    const u16* src;
+    if (u < kWptUnits) {
+        const int piece = (u >> 6) % 24, step = (u >> 6) / 24;
+        src = a.wp[blk] + (size_t)(piece * 16 + row16) * C + step * 32 + chunk;
+    } else {
+        const int v = (u - kWptUnits) >> 6, piece = v & 7, slice = (v >> 3) % 3, step = (v / 24) % G1S, ch = v / (24 * G1S);
+        src = a.w1[blk] + (size_t)(ch * HC + piece * 16 + row16) * C + step * G1W + slice * 32 + chunk;
+    }
+    u16* dst = a.out + (size_t)blk * (kWptUnits + kW1tUnits) * 8 + (size_t)u * 8;
+    *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
+}
+
 }  // namespace
 
 namespace equss {
 
+// Bytes of the stage images of one block's projection + fc1 weights, and the launch that writes them for `depth` blocks
+// (depth <= 16) into out[depth][tail_weight_image_bytes()]: first the Wp image, then the W1 image.
+size_t tail_weight_image_bytes() { return (size_t)(kWptUnits + kW1tUnits) * 16; }
+size_t tail_weight_wp_bytes() { return (size_t)kWptUnits * 16; }
+int pack_tail_weights(const void* const* wp, const void* const* w1, int depth, void* out, hipStream_t s) {
+    if (depth < 1 || depth > 16) return fail(EQUSS_E_UNSUPPORTED, "pack_tail_weights: depth=%d (1..16)", depth);
+    PackArgs a;
+    for (int i = 0; i < depth; ++i) {
+        if (!wp[i] || !w1[i] || ((uintptr_t)wp[i] % 16) || ((uintptr_t)w1[i] % 16))
+            return fail(EQUSS_E_ALIGN, "pack_tail_weights: weights must be non-null and 16-byte aligned");
+        a.wp[i] = reinterpret_cast<const u16*>(wp[i]);
+        a.w1[i] = reinterpret_cast<const u16*>(w1[i]);
+    }
+    a.out = reinterpret_cast<u16*>(out);
+    hipLaunchKernelGGL(pack_tail_weights_kernel, dim3((kWptUnits + kW1tUnits + 255) / 256, depth), dim3(256), 0, s, a);
+    return check_launch("pack_tail_weights_kernel");
+}
+
 bool mlp_fused_supports(int C_, int hidden) { return C_ == C && hidden == HID; }
 
 namespace {
-template <bool PROJ>
+template <bool PROJ, bool TILED>
 int launch_mlp(const MlpArgs& g, hipStream_t s) {
-    if (!lds_opt_in(reinterpret_cast<const void*>(mlp_kernel<PROJ>), kLds))
+    if (!lds_opt_in(reinterpret_cast<const void*>(mlp_kernel<PROJ, TILED>), kLds))
         return fail(EQUSS_E_UNSUPPORTED, "mlp_fused: cannot reserve %d bytes of LDS", kLds);
     const int ntiles = (g.M + BM - 1) / BM;
     const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(mlp_kernel<PROJ>, dim3(grid), dim3(kThreads), kLds, s, g);
+    hipLaunchKernelGGL((mlp_kernel<PROJ, TILED>), dim3(grid), dim3(kThreads), kLds, s, g);
     return check_launch("mlp_kernel");
 }
 }  // namespace
@@ -583,7 +655,8 @@ int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const
     g.W2 = reinterpret_cast<const u16*>(w2); g.b2 = b2;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta;
     g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps; g.M = M;
-    return launch_mlp<false>(g, s);
+    g.Wpt = nullptr; g.W1t = nullptr;
+    return launch_mlp<false, false>(g, s);
 }
 
 // The rest of a transformer block after attention in one kernel (vision_transformer.py:110-111):
@@ -592,7 +665,8 @@ int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const
 // same buffer, or null.
 int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, const float* gamma2, const float* beta2,
                 void* ln_mid, int64_t ld_mid, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
-                int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s) {
+                int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s,
+                const void* wp_image, const void* w1_image) {
     MlpArgs g;
     g.A0 = reinterpret_cast<const u16*>(att); g.lda0 = lda0;
     g.Wp = reinterpret_cast<const u16*>(wp); g.bp = bp; g.gamma2 = gamma2; g.beta2 = beta2;
@@ -601,7 +675,10 @@ int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, 
     g.W2 = reinterpret_cast<const u16*>(w2); g.b2 = b2;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta;
     g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln; g.eps = eps; g.M = M;
-    return launch_mlp<true>(g, s);
+    // stage images of the weights (pack_tail_weights), if the caller has them: ln_mid is then written in stage order too
+    g.Wpt = reinterpret_cast<const u16*>(wp_image); g.W1t = reinterpret_cast<const u16*>(w1_image);
+    if (wp_image && w1_image && ld_mid == C) return launch_mlp<true, true>(g, s);
+    return launch_mlp<true, false>(g, s);
 }
 
 }  // namespace equss
@@ -643,5 +720,5 @@ extern "C" int equss_block_tail_bf16(const void* att, int64_t ld_att, const void
         ((uintptr_t)w2 % 16) || ((uintptr_t)x % 16) || ((uintptr_t)ln_out % 16))
         return equss::fail(EQUSS_E_ALIGN, "block_tail: operands must be 16-byte aligned with padded leading dimensions");
     return equss::block_fused(att, ld_att, wp, bp, gamma2, beta2, ln_mid, ld_mid, w1, b1, w2, b2, x, ldx, gamma, beta, ln_out,
-                              ld_ln, M, eps, reinterpret_cast<hipStream_t>(stream));
+                              ld_ln, M, eps, reinterpret_cast<hipStream_t>(stream), nullptr, nullptr);
 }

@@ -12,7 +12,11 @@ int gemm8_patch_ln(const void* cols, int64_t lda, const void* W, int64_t ldw, co
 bool mlp_fused_supports(int C, int hidden);
 int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, const float* gamma2, const float* beta2,
                 void* ln_mid, int64_t ld_mid, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
-                int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
+                int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s,
+                const void* wp_image, const void* w1_image);
+size_t tail_weight_image_bytes();
+size_t tail_weight_wp_bytes();
+int pack_tail_weights(const void* const* wp, const void* const* w1, int depth, void* out, hipStream_t s);
 int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
               int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
 int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
@@ -150,8 +154,10 @@ PatchWs carve_patch(void* ws, int B, int H, int W, int P, int C) {
     return w;
 }
 
-struct VitWs { float* x; u16* ln; u16* qkv; u16* att; u16* hid; void* patch; size_t patch_bytes; size_t bytes; };
-VitWs carve_vit(void* ws, int C, int B, int H, int W, int P) {
+struct VitWs { float* x; u16* ln; u16* qkv; u16* att; u16* hid; void* patch; size_t patch_bytes; char* wimg; size_t bytes; };
+// wimg: ring-stage images of every block's projection + fc1 weights for the fused block-tail kernel (C = 384, up to 16
+// blocks: 1.4 MiB each, rewritten by every forward: the weights may have changed between two calls)
+VitWs carve_vit(void* ws, int C, int B, int H, int W, int P, int depth) {
     const size_t n = (size_t)(H / P) * (W / P);
     const size_t rows = (size_t)B * (n + 1);
     VitWs w;
@@ -165,6 +171,11 @@ VitWs carve_vit(void* ws, int C, int B, int H, int W, int P) {
     w.patch = base + off;
     w.patch_bytes = carve_patch(nullptr, B, H, W, P, C).bytes;
     off += w.patch_bytes;
+    w.wimg = nullptr;
+    if (equss::mlp_fused_supports(C, 4 * C) && depth >= 1 && depth <= 16) {
+        w.wimg = base + off;
+        off += align256(equss::tail_weight_image_bytes()) * depth;
+    }
     w.bytes = off;
     return w;
 }
@@ -294,7 +305,7 @@ int mlp_balanced(const void* a, int64_t lda, const void* w1, const float* b1, co
 // rows through the small-tile routes of the projection and of the MLP (same bits either way).
 int block_balanced(const void* att, const void* wp, const float* bp, const float* gamma2, const float* beta2, void* ln_mid,
                    const void* w1, const float* b1, const void* w2, const float* b2, float* x, const float* gamma,
-                   const float* beta, void* ln, void* hid, int M, float eps, hipStream_t s) {
+                   const float* beta, void* ln, void* hid, int M, float eps, hipStream_t s, const char* wimg) {
     const int C = 384, H = 1536;
     const int tiles = (M + 127) / 128, rounds = tiles / 256, rem = tiles % 256;
     const bool split = rounds >= 1 && rem != 0 && rem <= g_mlp_tail_max && hid;
@@ -302,7 +313,8 @@ int block_balanced(const void* att, const void* wp, const float* bp, const float
     int rc;
     {
         equss::ProfScope ps(EQUSS_K_BLOCK_TAIL, s);   // the fused launch alone; the trailing rows count under the GEMM classes
-        rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s);
+        rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s,
+                                wimg, wimg ? wimg + equss::tail_weight_wp_bytes() : nullptr);
     }
     if (rc || m_tail == 0) return rc;
     const u16* att_tail = reinterpret_cast<const u16*>(att) + (size_t)m_main * C;
@@ -413,14 +425,16 @@ extern "C" int equss_patch_tokens(const float* img, const void* w_patch, const f
 }
 
 int g_fuse_min_tiles = 384;
+int g_tail_images = 1;   // developer switch: ring-stage images of Wp / W1 for the fused block-tail kernel
 int g_mlp_fused = 2;   // developer switch: 2 = proj + MLP in one kernel, 1 = MLP in one kernel, 0 = one launch per GEMM
 extern "C" void equss_dev_mlp_fused(int on) { g_mlp_fused = on; }
 extern "C" void equss_dev_mlp_tail_max(int n) { g_mlp_tail_max = n; }
 extern "C" void equss_dev_fuse_min_tiles(int n) { g_fuse_min_tiles = n; }
+extern "C" void equss_dev_tail_images(int on) { g_tail_images = on; }
 
 extern "C" size_t equss_vit_workspace_bytes(const EqussVit* vit, int B, int H, int W) {
     if (!vit || B <= 0 || H <= 0 || W <= 0 || vit->patch <= 0) return 0;
-    return carve_vit(nullptr, vit->embed_dim, B, H, W, vit->patch).bytes;
+    return carve_vit(nullptr, vit->embed_dim, B, H, W, vit->patch, vit->depth).bytes;
 }
 
 // prepare_tokens, then per block: x += proj(attn(LN1 x)); x += fc2(gelu(fc1(LN2 x))); final norm on
@@ -435,7 +449,7 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
                      float* x_taps) {
     const int C = vit->embed_dim, P = vit->patch, heads = vit->heads;
     int rc;
-    VitWs w = carve_vit(workspace, C, B, H, W, P);
+    VitWs w = carve_vit(workspace, C, B, H, W, P, vit->depth);
     const int n = (H / P) * (W / P), N = n + 1, rows = B * N;
     bool ln0_done = false;   // block 0's norm1 came out of the patch embedding
     {
@@ -445,6 +459,18 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
                           vit->depth > 0 ? w.ln : nullptr, &ln0_done);
     }
     if (rc) return rc;
+    // The fused block-tail kernel reads the projection / fc1 weights as ring-stage images: written here, once per forward
+    // for all blocks (one launch, ~17 MB), when that kernel is going to run.
+    bool images = false;
+    if (g_tail_images && w.wimg && g_mlp_fused == 2 && (rows + 127) / 128 >= g_fuse_min_tiles && equss::gemm8_resid_ln_supports(C, C) &&
+        equss::mlp_fused_supports(C, 4 * C)) {
+        const void* wp[16]; const void* w1[16];
+        for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; }
+        equss::ProfScope ps(EQUSS_K_GEMM_PROJ, s);
+        rc = equss::pack_tail_weights(wp, w1, vit->depth, w.wimg, s);
+        if (rc) return rc;
+        images = true;
+    }
     const float scale = 0.125f;  // head_dim ** -0.5 with head_dim = 64 (vision_transformer.py:71-72)
 #define EQUSS_STEP(cls, call)                 \
     {                                         \
@@ -468,7 +494,8 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
         const bool big = (rows + 127) / 128 >= g_fuse_min_tiles;
         if (fuse && big && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
-            return block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s);
+            return block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s,
+                                  images ? w.wimg + (size_t)i * align256(equss::tail_weight_image_bytes()) : nullptr);
         }
         if (fuse) {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, resid_ln_balanced(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))

@@ -31,6 +31,8 @@ void equss_dev_mlp_fused(int on);
 void equss_dev_mlp_tail_max(int tiles);
 /* smallest number of 128-row tiles from which the fused kernels are used (default 384). */
 void equss_dev_fuse_min_tiles(int tiles);
+/* 1 (default): the fused block-tail kernel reads Wp / W1 as ring-stage images written at the start of the forward; 0: row-major. */
+void equss_dev_tail_images(int on);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@
 
 static unsigned short bf16(float f) { unsigned u; memcpy(&u, &f, 4); return (unsigned short)((u + 0x7fff + ((u >> 16) & 1)) >> 16); }
 
-int main() {
+int main(int argc, char**) {
     const int rows = 768 * 128, c = 384, hid = 1536;
     std::mt19937 gen(1);
     std::normal_distribution<float> nd;
@@ -23,10 +23,18 @@ int main() {
     float* g2 = dev_f32(c, 0.f, 1.f); float* be2 = dev_f32(c, 0.f, 0.f); float* ga = dev_f32(c, 0.f, 1.f); float* be = dev_f32(c, 0.f, 0.f);
     float* x = dev_f32((size_t)rows * c, 1.f, 0.f);
     void *mid, *ln; hipMalloc(&mid, (size_t)rows * c * 2); hipMalloc(&ln, (size_t)rows * c * 2);
+    char* img = nullptr;   // argument "images": the weights as ring-stage images (what the ViT forward uses)
+    if (argc > 1) {
+        hipMalloc(&img, equss::tail_weight_image_bytes());
+        const void* wps[1] = {wp}; const void* w1s[1] = {w1};
+        printf("pack rc %d\n", equss::pack_tail_weights(wps, w1s, 1, img, nullptr));
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 4; ++it) {
         hipEventRecord(e0);
-        int rc = equss_block_tail_bf16(att, c, wp, bp, g2, be2, mid, c, w1, b1, w2, b2, x, c, ga, be, ln, c, rows, c, hid, 1e-6f, nullptr);
+        int rc;
+        if (img) rc = equss::block_fused(att, c, wp, bp, g2, be2, mid, c, w1, b1, w2, b2, x, c, ga, be, ln, c, rows, 1e-6f, nullptr, img, img + equss::tail_weight_wp_bytes());
+        else rc = equss_block_tail_bf16(att, c, wp, bp, g2, be2, mid, c, w1, b1, w2, b2, x, c, ga, be, ln, c, rows, c, hid, 1e-6f, nullptr);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("rc %d, %.1f us\n", rc, ms * 1e3);

@@ -144,5 +144,10 @@ int main() {
     run<32, 4, 0, 10, 1024>(shared, own, out);  // ... or the consumers' LDS reads
     run<32, 4, 0, 10, 1>(shared, own, out);
     run<32, 4, 24, 0, 1024>(shared, own, out);  // ... or their MFMAs
+    run<32, 4, 12, 8, 1024>(shared, own, out);  // 64-row tiles: half the MFMAs per stage
+    run<32, 4, 12, 12, 1024>(shared, own, out);
+    run<32, 4, 16, 10, 1024>(shared, own, out);
+    run<24, 5, 12, 8, 1024>(shared, own, out);
+    run<48, 3, 24, 16, 1024>(shared, own, out);
     return 0;
 }
