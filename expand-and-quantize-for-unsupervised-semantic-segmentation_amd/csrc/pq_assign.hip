@@ -331,7 +331,9 @@ constexpr int kScrWaveLds = kScrRows * 256 + kScrRows * 4 * 2 + kScrRows * kScrC
 // NWAVES independent waves per workgroup: 12 (three per SIMD, <= 168 VGPRs) when the fp16 codebook
 // takes <= 64 KiB of LDS, 6 when it takes up to 128 KiB (K = 512).  MW = 32-bit survivor-mask words
 // per lane = K / 128.
-template <int D, int NWAVES, int MW>
+// KEEP: the scores of pass 1 stay in registers (K / 4 per lane) and pass 2 only compares them: half the MFMAs and
+// fragment reads, for eight waves of 256 registers instead of twelve of 168 (K = 128 MW exactly).
+template <int D, int NWAVES, int MW, bool KEEP = false>
 __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_kernel(const PqArgs a) {
     constexpr int kScrThreads = NWAVES * 64;
     static_assert(D == 128, "fragment and swizzle arithmetic below is written for d = 128");
@@ -423,6 +425,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
             *reinterpret_cast<uint2*>(zb + r * ROWB + (((c4 >> 1) ^ (r & 15)) * 16) + (c4 & 1) * 8) = pk;
         }
         if (lane < kScrRows) cnt_s[lane] = 0;
+        if constexpr (KEEP) fetch(tile + nwaves);   // (room for the next tile's rows from the start: the whole tile to land)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // same-wave LDS writes are visible to its reads
         // B fragments: lane (j, q) holds zn[j][32 t + 8 q .. + 7]
         f16x8 bf[KB];
@@ -445,10 +448,20 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
         PQ_STAMP(1);
         // ---- pass 1: best and second-best score per row ------------------------------------------------
         float best = -__builtin_inff();
-        for (int ct = 0; ct < K / 16; ct += 2) {
-            const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
-            best = fmaxf(fmaxf(fmaxf(fmaxf(best, a0.x), a0.y), a0.z), a0.w);   // (chains of three fold into v_max3_f32)
-            best = fmaxf(fmaxf(fmaxf(fmaxf(best, a1.x), a1.y), a1.z), a1.w);
+        constexpr int NCT = 8 * MW;
+        f32x4 sc[KEEP ? NCT : 1];
+        if constexpr (KEEP) {
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                sc[ct] = scores(ct);
+                best = fmaxf(fmaxf(fmaxf(fmaxf(best, sc[ct].x), sc[ct].y), sc[ct].z), sc[ct].w);
+            }
+        } else {
+            for (int ct = 0; ct < K / 16; ct += 2) {
+                const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
+                best = fmaxf(fmaxf(fmaxf(fmaxf(best, a0.x), a0.y), a0.z), a0.w);   // (chains of three fold into v_max3_f32)
+                best = fmaxf(fmaxf(fmaxf(fmaxf(best, a1.x), a1.y), a1.z), a1.w);
+            }
         }
         best = fmaxf(best, __shfl_xor(best, 16, 64));   // the four lanes that share a row
         best = fmaxf(best, __shfl_xor(best, 32, 64));
@@ -471,6 +484,14 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
         for (int w = 0; w < MW; ++w) mk[w] = ~0u;   // survivors are shifted in as zero bits; inverted below
 #pragma unroll
         for (int w = 0; w < MW; ++w) {
+            if constexpr (KEEP) {
+#pragma unroll
+                for (int ct = 8 * w; ct < 8 * w + 8; ++ct)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) mk[w] = shift_in_sign(mk[w], sc[ct][e] - thr);
+                mk[w] = row_finite ? ~mk[w] : 0u;
+                continue;
+            }
             const int ct_end = min(nct, 8 * w + 8);
             for (int ct = 8 * w; ct < ct_end; ct += 2) {
                 const f32x4 a0 = scores(ct), a1 = scores(ct + 1);
@@ -484,7 +505,7 @@ __global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_k
         // The next tile's rows are requested only now: they then occupy registers while the survivor
         // lists, the occasional exact re-scoring and the gather run (several microseconds, enough for the
         // loads to land), not during the two MFMA passes, whose fragments need the room.
-        fetch(tile + nwaves);
+        if constexpr (!KEEP) fetch(tile + nwaves);
         PQ_STAMP(3);
         auto codeword = [&](int w, int bit) {   // bit of word w -> codeword index
             const int n = 4 * min(nct - 8 * w, 8) - 1 - bit;
@@ -685,7 +706,7 @@ bool make_plan(int K, int d, PqPlan* pl) {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int g_pq_mode = 0;  // 0: screened search where it applies; 1: exact fp32 search everywhere
+int g_pq_mode = 0;  // 0: screened search where it applies; 1: exact fp32 search everywhere; 2: as 0 without the K = 256 variant
 
 struct PqWorkspace { float* cn; float* csq; float* loss_partial; size_t bytes; };
 
@@ -842,11 +863,12 @@ int pq_assign_impl(const float* code, int64_t ld_code, const float* codebooks, i
     if (screened) {
         a.ntiles = (rows + kScrRows - 1) / kScrRows;
         const bool small = (size_t)K * d * 2 <= 65536;
-        const int waves = small ? 12 : 6;
+        const bool keep = g_pq_mode != 2 && K == 256;   // pass-1 scores kept in registers (mode 2: the twelve-wave kernel)
+        const int waves = keep ? 8 : small ? 12 : 6;
         if (gx > (a.ntiles + waves - 1) / waves) gx = (a.ntiles + waves - 1) / waves;
         if (gx > kMaxGridX) gx = kMaxGridX;
         const size_t lds = (size_t)K * d * 2 + (K + 16) * 4 + (size_t)waves * kScrWaveLds;
-        void (*kern)(const PqArgs) = !small ? pq_screen_kernel<128, 6, 4> : (K <= 128 ? pq_screen_kernel<128, 12, 1> : pq_screen_kernel<128, 12, 2>);
+        void (*kern)(const PqArgs) = keep ? pq_screen_kernel<128, 8, 2, true> : !small ? pq_screen_kernel<128, 6, 4> : (K <= 128 ? pq_screen_kernel<128, 12, 1> : pq_screen_kernel<128, 12, 2>);
         if (!equss::lds_opt_in(reinterpret_cast<const void*>(kern), 163840))
             return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve LDS for the screened search");
         {

@@ -142,6 +142,15 @@ def test_screened_search_equals_exact_search(kind, rows, k, native, oracle, dev)
     # the screened kernel is deterministic run to run, loss included
     idx_2, zq_2, loss_2 = native.pq_assign(code.to(dev), books.to(dev))
     assert torch.equal(idx_2, idx_s) and torch.equal(zq_2, zq_s) and torch.equal(loss_2, loss_s)
+    if k == 256:   # K = 256 has two screened kernels (scores kept in registers / scored twice): same bits
+        import ctypes
+        try:
+            native.load_library().equss_dev_pq_mode(ctypes.c_int(2))
+            idx_3, zq_3, loss_3 = native.pq_assign(code.to(dev), books.to(dev))
+        finally:
+            _force_exact(native, False)
+        assert torch.equal(idx_3, idx_s) and torch.equal(zq_3, zq_s)
+        assert torch.allclose(loss_3, loss_s, rtol=1e-5)   # (per-workgroup partial sums: 8 waves against 12)
 
 
 def test_training_quantiser_gradients_match_autograd(pkg, dev):
@@ -185,7 +194,7 @@ def test_rows_with_nan_or_inf_get_index_zero(native, dev):
     dist = (z ** 2).sum(-1, keepdim=True).permute(1, 0, 2) + (cn ** 2).sum(-1).unsqueeze(1) - 2 * torch.einsum("npd,pkd->pnk", z, cn)
     want = dist.argmin(dim=-1)
     assert want[1, 5] == 0 and want[0, 17] == 0
-    for mode in (0, 1):
+    for mode in (0, 1, 2):
         native.load_library().equss_dev_pq_mode(ctypes.c_int(mode))
         try:
             idx, zq, loss = native.pq_assign(code.to(dev), books.to(dev))
