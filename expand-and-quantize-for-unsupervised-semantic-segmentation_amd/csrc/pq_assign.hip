@@ -332,9 +332,10 @@ constexpr int kScrWaveLds = kScrRows * 256 + kScrRows * 4 * 2 + kScrRows * kScrC
 // takes <= 64 KiB of LDS, 6 when it takes up to 128 KiB (K = 512).  MW = 32-bit survivor-mask words
 // per lane = K / 128.
 // KEEP: the scores of pass 1 stay in registers (K / 4 per lane) and pass 2 only compares them: half the MFMAs and
-// fragment reads, for eight waves of 256 registers instead of twelve of 168 (K = 128 MW exactly).
+// fragment reads, for eight waves of 256 registers instead of twelve of 168 (K = 256), or four of 512 instead of six of
+// 256 (K = 512); K = 128 MW exactly.
 template <int D, int NWAVES, int MW, bool KEEP = false>
-__global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : 2) void pq_screen_kernel(const PqArgs a) {
+__global__ __launch_bounds__(NWAVES * 64, NWAVES == 12 ? 3 : NWAVES == 4 ? 1 : 2) void pq_screen_kernel(const PqArgs a) {
     constexpr int kScrThreads = NWAVES * 64;
     static_assert(D == 128, "fragment and swizzle arithmetic below is written for d = 128");
     constexpr int LPR = D / 4;            // lanes holding one row as float4 each
@@ -706,7 +707,7 @@ bool make_plan(int K, int d, PqPlan* pl) {
 
 size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-int g_pq_mode = 0;  // 0: screened search where it applies; 1: exact fp32 search everywhere; 2: as 0 without the K = 256 variant
+int g_pq_mode = 0;  // 0: screened search where it applies; 1: exact fp32 search everywhere; 2: as 0 without the kept-score variants
 
 struct PqWorkspace { float* cn; float* csq; float* loss_partial; size_t bytes; };
 
@@ -864,11 +865,12 @@ int pq_assign_impl(const float* code, int64_t ld_code, const float* codebooks, i
         a.ntiles = (rows + kScrRows - 1) / kScrRows;
         const bool small = (size_t)K * d * 2 <= 65536;
         const bool keep = g_pq_mode != 2 && K == 256;   // pass-1 scores kept in registers (mode 2: the twelve-wave kernel)
-        const int waves = keep ? 8 : small ? 12 : 6;
+        const bool keep4 = g_pq_mode != 2 && K == 512;   // K = 512: kept scores need one wave per SIMD (360 -> 320 us at 16 x 512)
+        const int waves = keep4 ? 4 : keep ? 8 : small ? 12 : 6;
         if (gx > (a.ntiles + waves - 1) / waves) gx = (a.ntiles + waves - 1) / waves;
         if (gx > kMaxGridX) gx = kMaxGridX;
         const size_t lds = (size_t)K * d * 2 + (K + 16) * 4 + (size_t)waves * kScrWaveLds;
-        void (*kern)(const PqArgs) = keep ? pq_screen_kernel<128, 8, 2, true> : !small ? pq_screen_kernel<128, 6, 4> : (K <= 128 ? pq_screen_kernel<128, 12, 1> : pq_screen_kernel<128, 12, 2>);
+        void (*kern)(const PqArgs) = keep4 ? pq_screen_kernel<128, 4, 4, true> : keep ? pq_screen_kernel<128, 8, 2, true> : !small ? pq_screen_kernel<128, 6, 4> : (K <= 128 ? pq_screen_kernel<128, 12, 1> : pq_screen_kernel<128, 12, 2>);
         if (!equss::lds_opt_in(reinterpret_cast<const void*>(kern), 163840))
             return equss::fail(EQUSS_E_UNSUPPORTED, "pq_assign: cannot reserve LDS for the screened search");
         {

@@ -14,7 +14,7 @@ extern "C" {
 #endif
 
 /* 0 (default): screened fp16 search where it applies; 1: exhaustive fp32 search for every shape;
- * 2: as 0, but K = 256 on the twelve-wave kernel that scores every codeword twice instead of keeping the scores. */
+ * 2: as 0, but K = 256 / 512 on the twelve- / six-wave kernels that score every codeword twice instead of keeping the scores. */
 void equss_dev_pq_mode(int mode);
 /* equss_gemm_bf16 instance: 3 (default) large-tile ring kernel where it applies; 0..2 older 128x128 kernels. */
 void equss_dev_gemm_variant(int variant);
