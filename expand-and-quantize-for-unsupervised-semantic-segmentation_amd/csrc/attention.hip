@@ -116,8 +116,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
                 ks = base + (size_t)key * ld + C + k_chunk(st_row);
                 vs = base + (size_t)key * ld + 2 * C + v_chunk(st_row);
             }
+#ifndef EQUSS_ABL_ATTNOSTAGE
             glds16(ks, sb + p * 1024);
             glds16(vs, sb + kTile + p * 1024);
+#else
+            if (t < 2) { glds16(ks, sb + p * 1024); glds16(vs, sb + kTile + p * 1024); }
+#endif
         }
     };
 
@@ -201,9 +205,17 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
             psum = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+#ifndef EQUSS_ABL_ATTNOEXP   // (EQUSS_ABL_*: developer builds that leave one cost out, tools/build_ablations.sh; wrong results by design)
                 s0[r] = __builtin_amdgcn_exp2f(s0[r]);
                 s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+#else
+                s0[r] = fmaf(s0[r], 1e-9f, 0.01f); s1[r] = fmaf(s1[r], 1e-9f, 0.01f);
+#endif
+#ifndef EQUSS_ABL_ATTNOSUM
                 psum += s0[r] + s1[r];
+#else
+                if (r == 0) psum += s0[r] + s1[r];
+#endif
             }
         };
         scores();
@@ -249,7 +261,11 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
                 for (int j = 0; j < 4; ++j) {
                     const float lo = u == 0 ? s0[8 * sp + 2 * j] : s1[8 * sp + 2 * j];
                     const float hi = u == 0 ? s0[8 * sp + 2 * j + 1] : s1[8 * sp + 2 * j + 1];
+#ifndef EQUSS_ABL_ATTNOCVT
                     pf.w[j] = equss::pack_bf16(lo, hi);
+#else
+                    pf.w[j] = __builtin_bit_cast(uint32_t, lo) ^ __builtin_bit_cast(uint32_t, hi);
+#endif
                 }
                 const int krow = (32 * u + 16 * sp) * 128;
 #pragma unroll
@@ -257,8 +273,12 @@ __global__ __launch_bounds__(NW * 64, 4) void attention_kernel(const AttnArgs a)
                     union { bf16x8 v; bf16x4 hlf[2]; } vf;
                     vf.hlf[0] = ds_read_tr16(vb + krow + v_off[dt]);
                     vf.hlf[1] = ds_read_tr16(vb + krow + 8 * 128 + v_off[dt]);
+#ifndef EQUSS_ABL_ATTNOPV
                     if (dt == 0) o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o0, 0, 0, 0);
                     else         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf.v, pf.v, o1, 0, 0, 0);
+#else
+                    asm volatile("" ::"v"(vf.v), "v"(pf.v));
+#endif
                 }
             }
         }
