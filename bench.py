@@ -36,7 +36,7 @@ PEAK_HBM = 8.0e12           # B/s
 PEAK_FP32 = 157.3e12        # FLOP/s (vector = f32 MFMA rate)
 
 
-def algorithmic_work(cfg, batch, height, width):
+def algorithmic_work(cfg, batch, height, width, block_ws=True):
     """FLOPs (2 M N K, no recompute) and bytes per LAUNCH of each kernel class for one batch."""
     from_cfg = cfg["model"]
     c = {"vit_small": 384, "vit_base": 768}[from_cfg["pretrained"]["model_type"]]
@@ -51,7 +51,9 @@ def algorithmic_work(cfg, batch, height, width):
     # the 256 CUs (proj + MLP), the trailing rows go through one small launch per GEMM (vit_ops.hip)
     tiles = (rows + 127) // 128
     fused = c == 384 and tiles >= 384
-    split = fused and tiles // 256 >= 1 and 0 < tiles % 256 <= 128
+    # (the default producer / consumer block-tail kernel takes all rows; the eight-wave one, --dev block_ws=0, only the
+    # whole rounds of 128-row tiles)
+    split = fused and not block_ws and tiles // 256 >= 1 and 0 < tiles % 256 <= 128
     rows_fused = (tiles // 256) * 256 * 128 if split else (rows if fused else 0)
     rows_gemm = rows - rows_fused          # rows the per-GEMM launches of proj / fc1 / fc2 see
     w = {
@@ -162,7 +164,9 @@ def main():
             dist.destroy_process_group()
         return
 
-    work = algorithmic_work(cfg, args.batch, args.res, args.res)
+    knobs = dict(kv.split("=") for kv in args.dev)
+    work = algorithmic_work(cfg, args.batch, args.res, args.res,
+                            block_ws=int(knobs.get("block_ws", 1)) != 0 and int(knobs.get("tail_images", 1)) != 0)
     # HBM bytes per launch from the PMC counters are measured by separate rocprofv3 passes (profiles/): they
     # are quoted only while the kernel sources still hash to what those passes ran, otherwise null
     traffic = {}

@@ -16,7 +16,12 @@ int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, 
                 const void* wp_image, const void* w1_image);
 size_t tail_weight_image_bytes();
 size_t tail_weight_wp_bytes();
-int pack_tail_weights(const void* const* wp, const void* const* w1, int depth, void* out, hipStream_t s);
+size_t tail_weight_w1_bytes();
+int pack_tail_weights(const void* const* wp, const void* const* w1, const void* const* w2, int depth, void* out, hipStream_t s);
+bool block_ws_enabled();
+int block_ws(const void* att, int64_t lda0, const void* wp_image, const void* w1_image, const void* w2_image, const float* bp,
+             const float* gamma2, const float* beta2, const float* b1, const float* b2, float* x, int64_t ldx, const float* gamma,
+             const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
 int mlp_fused(const void* a, int64_t lda, const void* w1, const float* b1, const void* w2, const float* b2, float* x,
               int64_t ldx, const float* gamma, const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
 int gemm8_resid_ln(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, int64_t ldx,
@@ -307,14 +312,22 @@ int block_balanced(const void* att, const void* wp, const float* bp, const float
                    const void* w1, const float* b1, const void* w2, const float* b2, float* x, const float* gamma,
                    const float* beta, void* ln, void* hid, int M, float eps, hipStream_t s, const char* wimg) {
     const int C = 384, H = 1536;
+    const bool ws = wimg && equss::block_ws_enabled();   // the producer / consumer kernel works on 64-row tiles
+    // (its 64-row tiles make a partly filled last round cheaper than the small-tile launches for the trailing rows: 10.35
+    // against 10.62 ms per 64-image forward on one stream, 9.8 against 10.3 ms on two: it takes all rows)
     const int tiles = (M + 127) / 128, rounds = tiles / 256, rem = tiles % 256;
-    const bool split = rounds >= 1 && rem != 0 && rem <= g_mlp_tail_max && hid;
+    const bool split = !ws && rounds >= 1 && rem != 0 && rem <= g_mlp_tail_max && hid;
     const int m_main = split ? rounds * 256 * 128 : M, m_tail = M - m_main;
     int rc;
     {
         equss::ProfScope ps(EQUSS_K_BLOCK_TAIL, s);   // the fused launch alone; the trailing rows count under the GEMM classes
-        rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s,
-                                wimg, wimg ? wimg + equss::tail_weight_wp_bytes() : nullptr);
+        if (ws)
+            rc = equss::block_ws(att, C, wimg, wimg + equss::tail_weight_wp_bytes(),
+                                 wimg + equss::tail_weight_wp_bytes() + equss::tail_weight_w1_bytes(), bp, gamma2, beta2, b1, b2, x, C,
+                                 gamma, beta, ln, C, m_main, eps, s);
+        else
+            rc = equss::block_fused(att, C, wp, bp, gamma2, beta2, ln_mid, C, w1, b1, w2, b2, x, C, gamma, beta, ln, C, m_main, eps, s,
+                                    wimg, wimg ? wimg + equss::tail_weight_wp_bytes() : nullptr);
     }
     if (rc || m_tail == 0) return rc;
     const u16* att_tail = reinterpret_cast<const u16*>(att) + (size_t)m_main * C;
@@ -464,10 +477,10 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
     bool images = false;
     if (g_tail_images && w.wimg && g_mlp_fused == 2 && (rows + 127) / 128 >= g_fuse_min_tiles && equss::gemm8_resid_ln_supports(C, C) &&
         equss::mlp_fused_supports(C, 4 * C)) {
-        const void* wp[16]; const void* w1[16];
-        for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; }
+        const void* wp[16]; const void* w1[16]; const void* w2[16];
+        for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; w2[i] = vit->blocks[i].fc2_w; }
         equss::ProfScope ps(EQUSS_K_GEMM_PROJ, s);
-        rc = equss::pack_tail_weights(wp, w1, vit->depth, w.wimg, s);
+        rc = equss::pack_tail_weights(wp, w1, w2, vit->depth, w.wimg, s);
         if (rc) return rc;
         images = true;
     }

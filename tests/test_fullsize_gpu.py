@@ -128,3 +128,25 @@ def test_bcfg_at_its_real_shape_768px(pkg, native, oracle, dev):
     err = float((got[n:2 * n, h * 64:(h + 1) * 64].double() - ref).norm() / ref.norm())
     print("attention at N = 9217, rel-L2 vs fp64:", err)
     assert err < 1e-2
+
+
+def test_block_tail_kernels_give_equal_bits_inside_the_vit(pkg, native, dev):
+    """The producer / consumer block-tail kernel (64-row tiles, the default inside the ViT forward) against the eight-wave
+    kernel + small-tile launches it replaces: equal bits of the features, at a row count that leaves a ragged last tile
+    (37 x 1601 rows) and at one that does not divide into rounds either way."""
+    import ctypes
+    lib = native.load_library()
+    torch.manual_seed(3)
+    net = pkg.featurizer.vit_small(patch_size=8).to(dev).eval()
+    for batch in (37, 48):
+        img = torch.randn(batch, 3, 320, 320, device=dev)
+        feats = []
+        try:
+            for on in (1, 0):
+                lib.equss_dev_block_ws(ctypes.c_int(on))
+                with torch.no_grad():
+                    feats.append(net.get_intermediate_feat(img, n=1)[0][0].clone())
+        finally:
+            lib.equss_dev_block_ws(ctypes.c_int(1))
+        assert torch.isfinite(feats[0]).all()
+        assert torch.equal(feats[0], feats[1])

@@ -26,8 +26,8 @@ int main(int argc, char**) {
     char* img = nullptr;   // argument "images": the weights as ring-stage images (what the ViT forward uses)
     if (argc > 1) {
         hipMalloc(&img, equss::tail_weight_image_bytes());
-        const void* wps[1] = {wp}; const void* w1s[1] = {w1};
-        printf("pack rc %d\n", equss::pack_tail_weights(wps, w1s, 1, img, nullptr));
+        const void* wps[1] = {wp}; const void* w1s[1] = {w1}; const void* w2s[1] = {w2};
+        printf("pack rc %d\n", equss::pack_tail_weights(wps, w1s, w2s, 1, img, nullptr));
     }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     for (int it = 0; it < 4; ++it) {
