@@ -46,7 +46,12 @@ static_assert(kLds <= 163840, "LDS budget");
 typedef equss::lds_u32x4 L4;
 template <int OFF> __device__ __forceinline__ L4 LD(uint32_t a) { return equss::lds_load_b128_at<OFF>(a); }
 __device__ __forceinline__ f32x4 MM(const L4& a, const L4& b, f32x4 c) {
+#ifndef EQUSS_ABL_BWNOMFMA   // (EQUSS_ABL_*: developer builds that leave one cost out, tools/build_ablations.sh; wrong results by design)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#else
+    asm volatile("" ::"v"(a), "v"(b));
+    return c;
+#endif
 }
 __device__ __forceinline__ f32x4 as_f32x4(const L4& v) { return __builtin_bit_cast(f32x4, v); }
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -107,6 +112,9 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
                 src = r < G1S ? g.W1t + (c * G1S + r) * kImg : g.W2t + (c * G2S + (r - G1S)) * kImg;
             }
             char* base = smem + i_buf * kStage;
+#ifdef EQUSS_ABL_BWNODMA
+            if (issued < 2)
+#endif
 #pragma unroll
             for (int i = 0; i < PW; ++i) glds16(src + img_lane + i * (NP * 512), base + (pw + NP * i) * 1024);
             ++issued;
@@ -167,20 +175,41 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
         return base;
     };
 
-    int c_tile = slot;
-    request_att(x_start + c_tile);
-    for (int t = 0; t < my_tiles; ++t, c_tile += nslots) {
-        const int m0 = (x_start + c_tile) * BM;
-        float* xrow = g.x + (size_t)(m0 + wm * 32 + fr) * g.ldx + wn * 96 + fq * 4;   // + mt * 16 rows, + nt * 16
-        const bool row_ok[2] = {m0 + wm * 32 + fr < g.M, m0 + wm * 32 + 16 + fr < g.M};   // (only the last tile can be ragged)
-        f32x4 acc2[6][2];   // [nt][mt]: rows wm*32 + mt*16 + fr, columns wn*96 + nt*16 + fq*4 + 0..3
+    // The residual rows of a tile are requested before the previous tile's epilogue: they come from memory while that
+    // tile's statistics, LayerNorm rows and stores are under way, and the wait at the start of the tile leaves those
+    // stores in flight.
+    f32x4 xn[6][2];
+    auto request_x = [&](int logical) {
+        const int r0 = logical * BM + wm * 32 + fr;
+        const float* xr = g.x + (size_t)r0 * g.ldx + wn * 96 + fq * 4;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
-                acc2[nt][mt] = row_ok[mt] ? *reinterpret_cast<const f32x4*>(xrow + (size_t)(mt * 16) * g.ldx + nt * 16)
-                                          : f32x4{0.f, 0.f, 0.f, 0.f};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // residual rows here, this wave's attention pieces in LDS
+#ifndef EQUSS_ABL_BWNOX
+                xn[nt][mt] = r0 + mt * 16 < g.M ? *reinterpret_cast<const f32x4*>(xr + (size_t)(mt * 16) * g.ldx + nt * 16)
+                                                : f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+                xn[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+    };
+    int c_tile = slot;
+    request_att(x_start + c_tile);
+    request_x(x_start + c_tile);
+    for (int t = 0; t < my_tiles; ++t, c_tile += nslots) {
+        const int m0 = (x_start + c_tile) * BM;
+        float* xrow = g.x + (size_t)(m0 + wm * 32 + fr) * g.ldx + wn * 96 + fq * 4;   // + mt * 16 rows, + nt * 16
+        const bool row_ok[2] = {m0 + wm * 32 + fr < g.M, m0 + wm * 32 + 16 + fr < g.M};   // (only the last tile can be ragged)
+        // residual rows here, this wave's attention pieces in LDS; younger than both are only the previous tile's stores
+        // (a tile with a successor is full: 12 stores of x, 12 of the LayerNorm rows if they are wanted)
+        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (g.ln) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        f32x4 acc2[6][2];   // [nt][mt]: rows wm*32 + mt*16 + fr, columns wn*96 + nt*16 + fq*4 + 0..3
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 6; ++nt) acc2[nt][mt] = xn[nt][mt];
         {
             L4 b[6];
             const uint32_t sb = equss::lds_addr(biasp_s) + (wn * 96 + fq * 4) * 4;
@@ -234,29 +263,41 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
         };
         // LayerNorm of the rows in acc2 with scale / shift at gs / bs: fn(nt, mt, lo, hi) gets four bf16 as two dwords
         auto normalise = [&](const float* gs, const float* bs, auto&& fn) {
-            L4 gau[6], beu[6], pru[2][2];
+            // (scale / shift two column groups at a time: the next tile's residual rows may be waiting in 48 registers)
+            L4 pru[2][2];
             const uint32_t sg = equss::lds_addr(gs) + (wn * 96 + fq * 4) * 4, sb = equss::lds_addr(bs) + (wn * 96 + fq * 4) * 4;
             const uint32_t sp = equss::lds_addr(red_s) + (wm * 32 + fr) * WN * 8;
             pru[0][0] = LD<0>(sp); pru[0][1] = LD<16>(sp);
             pru[1][0] = LD<16 * WN * 8>(sp); pru[1][1] = LD<16 * WN * 8 + 16>(sp);
-            gau[0] = LD<0>(sg); gau[1] = LD<64>(sg); gau[2] = LD<128>(sg); gau[3] = LD<192>(sg); gau[4] = LD<256>(sg); gau[5] = LD<320>(sg);
-            beu[0] = LD<0>(sb); beu[1] = LD<64>(sb); beu[2] = LD<128>(sb); beu[3] = LD<192>(sb); beu[4] = LD<256>(sb); beu[5] = LD<320>(sb);
-            equss::lds_wait_for<0>(gau[0], gau[1], gau[2], gau[3], gau[4], gau[5], beu[0], beu[1], beu[2], beu[3], beu[4], beu[5],
-                                   pru[0][0], pru[0][1], pru[1][0], pru[1][1]);
+            equss::lds_wait_for<0>(pru[0][0], pru[0][1], pru[1][0], pru[1][1]);
+            float mean[2], rstd[2];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const f32x4 q0 = as_f32x4(pru[mt][0]), q1 = as_f32x4(pru[mt][1]);   // (sum, sum of squares) of the four waves
-                const float mean = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
+                mean[mt] = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
                 const float ex2 = ((q0.y + q0.w) + (q1.y + q1.w)) * (1.0f / C);
-                const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
-#pragma unroll
-                for (int nt = 0; nt < 6; ++nt) {
-                    const f32x4 ga = as_f32x4(gau[nt]), be = as_f32x4(beu[nt]);
-                    const f32x4 v = acc2[nt][mt];
-                    fn(nt, mt, equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y)),
-                       equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w)));
-                }
+                rstd[mt] = 1.0f / sqrtf(fmaxf(fmaf(-mean[mt], mean[mt], ex2), 0.f) + g.eps);
             }
+#pragma unroll
+            for (int np = 0; np < 3; ++np) {
+                L4 gau[2], beu[2];
+                gau[0] = equss::lds_load_b128(reinterpret_cast<const char*>(gs) + (wn * 96 + fq * 4) * 4 + np * 128);
+                gau[1] = equss::lds_load_b128(reinterpret_cast<const char*>(gs) + (wn * 96 + fq * 4) * 4 + np * 128 + 64);
+                beu[0] = equss::lds_load_b128(reinterpret_cast<const char*>(bs) + (wn * 96 + fq * 4) * 4 + np * 128);
+                beu[1] = equss::lds_load_b128(reinterpret_cast<const char*>(bs) + (wn * 96 + fq * 4) * 4 + np * 128 + 64);
+                equss::lds_wait_for<0>(gau[0], gau[1], beu[0], beu[1]);
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        const int nt = 2 * np + h;
+                        const f32x4 ga = as_f32x4(gau[h]), be = as_f32x4(beu[h]);
+                        const f32x4 v = acc2[nt][mt];
+                        fn(nt, mt, equss::pack_bf16(fmaf((v.x - mean[mt]) * rstd[mt], ga.x, be.x), fmaf((v.y - mean[mt]) * rstd[mt], ga.y, be.y)),
+                           equss::pack_bf16(fmaf((v.z - mean[mt]) * rstd[mt], ga.z, be.z), fmaf((v.w - mean[mt]) * rstd[mt], ga.w, be.w)));
+                    }
+            }
+            (void)sg; (void)sb;
         };
 
         // ---- G0: acc2 = x + bp + att Wp^T (12 steps of 32) ---------------------------------------------------
@@ -319,8 +360,12 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
                         const int row = wm * 32 + mt * 16 + fr;
                         f32x4 v = acc1[nt][mt];
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+#ifndef EQUSS_ABL_BWNOGELU
                         const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
                         const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
+#else
+                        const equss::gelu_f32x2 g0 = {v.x, v.y}, g1 = {v.z, v.w};
+#endif
                         equss::lds_store_b64(hc + half * 8192 + row * 128 + (((n6 >> 3) ^ ((row >> 1) & 7)) * 16) + ((n6 >> 2) & 1) * 8,
                                              equss::pack_bf16(g0.x, g0.y), equss::pack_bf16(g1.x, g1.y));
                     }
@@ -347,6 +392,15 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
                 if (c == NCH - 1 && ks == 0 && t + 1 < my_tiles) request_att(x_start + c_tile + nslots);
             }
         }
+        // the next tile's residual rows: requested here, under the epilogue (every path defines xn: its old value has
+        // been dead since the tile began, and a conditional definition would keep 48 registers alive across the tile)
+        if (t + 1 < my_tiles) request_x(x_start + c_tile + nslots);
+        else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < 6; ++nt) xn[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         // ---- epilogue: x back, LayerNorm of the final rows as bf16 -------------------------------------------------
         row_stats();
         if (g.ln) {
@@ -359,7 +413,11 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
+#ifndef EQUSS_ABL_BWNOX
                 if (row_ok[mt]) *reinterpret_cast<f32x4*>(xrow + (size_t)(mt * 16) * g.ldx + nt * 16) = acc2[nt][mt];
+#else
+                asm volatile("" ::"v"(acc2[nt][mt]));
+#endif
     }
 }
 
