@@ -32,7 +32,7 @@ struct BwArgs {
 };
 
 constexpr int C = 384, HID = 1536, BM = 64, HC = 128, NCH = HID / HC;
-constexpr int NC = 8, NP = 4, WN = 4, kThreads = (NC + NP) * 64;
+constexpr int NP = 4, WN = 4;
 constexpr int kStage = 24576, S = 3, PW = 24 / NP;     // 24 pieces of 1 KiB per stage, 6 per producer wave
 constexpr int G0S = C / 32, G1S = C / 96, G2S = HC / 32;
 constexpr int kTileStages = G0S + NCH * (G1S + G2S);    // 108
@@ -60,7 +60,30 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 }
 __device__ __forceinline__ int swz4(int q) { return (0x78 >> (2 * q)) & 3; }   // chunk swizzle of 64-byte rows (mlp_fused.hip)
 
-__global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
+// every fragment register of a group through the counted wait (equss::lds_wait_for for arrays)
+template <int N, int K1, int K2>
+__device__ __forceinline__ void wait_frags(L4 (&x)[K1], L4 (&y)[K2]) {
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+#pragma unroll
+    for (int i = 0; i < K1; ++i) equss::lds_tie(x[i]);
+#pragma unroll
+    for (int i = 0; i < K2; ++i) equss::lds_tie(y[i]);
+}
+// 16-row fragments i = 0 .. K - 1 at STRIDE bytes from each other
+template <int OFF, int STRIDE, int K>
+__device__ __forceinline__ void load_frags(L4 (&f)[K], uint32_t addr) {
+    static_assert(K == 2 || K == 4, "two or four 16-row fragments");
+    f[0] = LD<OFF>(addr); f[1] = LD<OFF + STRIDE>(addr);
+    if constexpr (K == 4) { f[2] = LD<OFF + 2 * STRIDE>(addr); f[3] = LD<OFF + 3 * STRIDE>(addr); }
+}
+
+// WM = consumer wave rows: 2 = eight consumer waves of 32 rows x 96 columns (12 waves, 168 registers each);
+// 1 = four consumer waves of 64 x 96, one per SIMD (8 waves, 256 registers each): 10 instead of 16 fragment reads per
+// 24 MFMAs, and the LDS reads are what the 32-row layout spends most of its time on.
+template <int WM>
+__global__ __launch_bounds__((4 * WM + NP) * 64, 1) void block_ws_kernel(const BwArgs g) {
+    constexpr int NC = 4 * WM, MT = 4 / WM, RW = BM / WM, kThreads = (NC + NP) * 64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -147,18 +170,18 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
     const int wm = wave / WN, wn = wave % WN;
     const int fr = lane & 15, fq = lane >> 4;
     const int g0_off = (fq ^ swz4((fr >> 2) & 3)) * 16;       // fragment read in a 64-byte-row slice: chunk fq of row fr
-    const uint32_t xs_a = equss::lds_addr(xs) + (wm * 32 + fr) * 64 + g0_off;            // + slice * 4096 + mt * 1024
+    const uint32_t xs_a = equss::lds_addr(xs) + (wm * RW + fr) * 64 + g0_off;            // + slice * 4096 + mt * 1024
     const uint32_t w96_off = (wn * 96 + fr) * 64 + g0_off;                              // Wp / W2 slice rows, + i * 1024
     const uint32_t w32_off = (wn * 32 + fr) * 64 + g0_off;                              // W1 slice rows, + sub * 8192 + i * 1024
     int c_off[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) c_off[ks] = ((4 * ks + fq) ^ ((fr >> 1) & 7)) * 16;   // 128-byte rows of the hidden tile
-    const uint32_t hc_a = equss::lds_addr(hc) + (wm * 32 + fr) * 128;                    // + half * 8192 + mt * 2048 + c_off
-    // attention rows of a tile -> xs, slice order: piece p (16 rows of one 32-wide slice) = wave + 8 i, i < 6
+    const uint32_t hc_a = equss::lds_addr(hc) + (wm * RW + fr) * 128;                    // + half * 8192 + mt * 2048 + c_off
+    // attention rows of a tile -> xs, slice order: piece p (16 rows of one 32-wide slice) = wave + NC i, i < 48 / NC
     const int st_row = lane >> 2, st_chunk = ((lane & 3) ^ swz4((lane >> 4) & 3)) * 8;
     auto request_att = [&](int logical) {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
+        for (int i = 0; i < 48 / NC; ++i) {
             const int p = wave + NC * i, slice = p >> 2, rp = p & 3;      // 4 pieces of 16 rows per slice
             int row = logical * BM + rp * 16 + st_row;
             if (row > g.M - 1) row = g.M - 1;   // rows past the end re-read the last row; their outputs are not stored
@@ -178,12 +201,12 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
     // The residual rows of a tile are requested before the previous tile's epilogue: they come from memory while that
     // tile's statistics, LayerNorm rows and stores are under way, and the wait at the start of the tile leaves those
     // stores in flight.
-    f32x4 xn[6][2];
+    f32x4 xn[6][MT];
     auto request_x = [&](int logical) {
-        const int r0 = logical * BM + wm * 32 + fr;
+        const int r0 = logical * BM + wm * RW + fr;
         const float* xr = g.x + (size_t)r0 * g.ldx + wn * 96 + fq * 4;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
 #ifndef EQUSS_ABL_BWNOX
@@ -198,16 +221,19 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
     request_x(x_start + c_tile);
     for (int t = 0; t < my_tiles; ++t, c_tile += nslots) {
         const int m0 = (x_start + c_tile) * BM;
-        float* xrow = g.x + (size_t)(m0 + wm * 32 + fr) * g.ldx + wn * 96 + fq * 4;   // + mt * 16 rows, + nt * 16
-        const bool row_ok[2] = {m0 + wm * 32 + fr < g.M, m0 + wm * 32 + 16 + fr < g.M};   // (only the last tile can be ragged)
-        // residual rows here, this wave's attention pieces in LDS; younger than both are only the previous tile's stores
-        // (a tile with a successor is full: 12 stores of x, 12 of the LayerNorm rows if they are wanted)
-        if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (g.ln) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        f32x4 acc2[6][2];   // [nt][mt]: rows wm*32 + mt*16 + fr, columns wn*96 + nt*16 + fq*4 + 0..3
+        float* xrow = g.x + (size_t)(m0 + wm * RW + fr) * g.ldx + wn * 96 + fq * 4;   // + mt * 16 rows, + nt * 16
+        bool row_ok[MT];   // (only the last tile can be ragged)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt) row_ok[mt] = m0 + wm * RW + mt * 16 + fr < g.M;
+        // residual rows here, this wave's attention pieces in LDS; younger than both are only the previous tile's stores
+        // (a tile with a successor is full: 6 MT stores of x, as many of the LayerNorm rows if they are wanted)
+        if (WM == 1 && t > 0) request_x(x_start + c_tile);   // (one wave per SIMD: no room to hold them across the epilogue)
+        if (t == 0 || WM == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (g.ln) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * MT) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * MT) : "memory");
+        f32x4 acc2[6][MT];   // [nt][mt]: rows wm*32 + mt*16 + fr, columns wn*96 + nt*16 + fq*4 + 0..3
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt) acc2[nt][mt] = xn[nt][mt];
         {
@@ -218,34 +244,37 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
+                for (int mt = 0; mt < MT; ++mt) {
                     const f32x4 b4 = as_f32x4(b[nt]);
                     acc2[nt][mt].x += b4.x; acc2[nt][mt].y += b4.y; acc2[nt][mt].z += b4.z; acc2[nt][mt].w += b4.w;
                 }
         }
         // one 32-wide step of acc2 += A W^T: A fragments at `sa` (+ 1024 per 16 rows), weight slice rows at `sw`
         auto step96 = [&](uint32_t sa, uint32_t sw, auto a_stride) {   // a_stride: bytes from one 16-row A fragment to the next
-            L4 a[2], w[6];
-            a[0] = LD<0>(sa); a[1] = LD<decltype(a_stride)::value>(sa);
+            L4 a[MT], w[6];
+            load_frags<0, decltype(a_stride)::value>(a, sa);
             w[0] = LD<0>(sw); w[1] = LD<1024>(sw); w[2] = LD<2048>(sw);
             w[3] = LD<3072>(sw); w[4] = LD<4096>(sw); w[5] = LD<5120>(sw);
             __builtin_amdgcn_s_setprio(1);
-            equss::lds_wait_for<3>(a[0], a[1], w[0], w[1], w[2]);
+            {
+                L4 (&w012)[3] = reinterpret_cast<L4 (&)[3]>(w[0]);
+                wait_frags<3>(a, w012);
+            }
 #pragma unroll
             for (int nt = 0; nt < 3; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = MM(w[nt], a[mt], acc2[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt) acc2[nt][mt] = MM(w[nt], a[mt], acc2[nt][mt]);
             equss::lds_wait_for<0>(w[3], w[4], w[5]);
 #pragma unroll
             for (int nt = 3; nt < 6; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = MM(w[nt], a[mt], acc2[nt][mt]);
+                for (int mt = 0; mt < MT; ++mt) acc2[nt][mt] = MM(w[nt], a[mt], acc2[nt][mt]);
             __builtin_amdgcn_s_setprio(0);
         };
         // row sums of acc2 -> red_s (in-lane, two shuffles, then one value per wave and row)
         auto row_stats = [&]() {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 float s1 = 0.f, s2 = 0.f;
 #pragma unroll
                 for (int nt = 0; nt < 6; ++nt) {
@@ -255,7 +284,7 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
                 }
                 s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
                 s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
-                if (fq == 0) equss::lds_store_f32x2(red_s + ((wm * 32 + mt * 16 + fr) * WN + wn), s1, s2);
+                if (fq == 0) equss::lds_store_f32x2(red_s + ((wm * RW + mt * 16 + fr) * WN + wn), s1, s2);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -264,15 +293,23 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
         // LayerNorm of the rows in acc2 with scale / shift at gs / bs: fn(nt, mt, lo, hi) gets four bf16 as two dwords
         auto normalise = [&](const float* gs, const float* bs, auto&& fn) {
             // (scale / shift two column groups at a time: the next tile's residual rows may be waiting in 48 registers)
-            L4 pru[2][2];
+            L4 pru[MT][2];
             const uint32_t sg = equss::lds_addr(gs) + (wn * 96 + fq * 4) * 4, sb = equss::lds_addr(bs) + (wn * 96 + fq * 4) * 4;
-            const uint32_t sp = equss::lds_addr(red_s) + (wm * 32 + fr) * WN * 8;
+            const uint32_t sp = equss::lds_addr(red_s) + (wm * RW + fr) * WN * 8;
             pru[0][0] = LD<0>(sp); pru[0][1] = LD<16>(sp);
             pru[1][0] = LD<16 * WN * 8>(sp); pru[1][1] = LD<16 * WN * 8 + 16>(sp);
-            equss::lds_wait_for<0>(pru[0][0], pru[0][1], pru[1][0], pru[1][1]);
-            float mean[2], rstd[2];
+            if constexpr (MT == 4) {
+                pru[2][0] = LD<32 * WN * 8>(sp); pru[2][1] = LD<32 * WN * 8 + 16>(sp);
+                pru[3][0] = LD<48 * WN * 8>(sp); pru[3][1] = LD<48 * WN * 8 + 16>(sp);
+            }
+            {
+                L4 (&lo)[MT] = reinterpret_cast<L4 (&)[MT]>(pru[0][0]);
+                L4 (&hi)[MT] = reinterpret_cast<L4 (&)[MT]>(pru[MT / 2][0]);
+                wait_frags<0>(lo, hi);
+            }
+            float mean[MT], rstd[MT];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const f32x4 q0 = as_f32x4(pru[mt][0]), q1 = as_f32x4(pru[mt][1]);   // (sum, sum of squares) of the four waves
                 mean[mt] = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
                 const float ex2 = ((q0.y + q0.w) + (q1.y + q1.w)) * (1.0f / C);
@@ -289,7 +326,7 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt) {
                         const int nt = 2 * np + h;
                         const f32x4 ga = as_f32x4(gau[h]), be = as_f32x4(beu[h]);
                         const f32x4 v = acc2[nt][mt];
@@ -310,35 +347,35 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
         normalise(gamma2_s, beta2_s, [&](int nt, int mt, uint32_t lo, uint32_t hi) {
             // columns wn*96 + nt*16 + fq*4 .. + 3: slice wn*3 + nt/2, chunk (nt & 1) * 2 + fq / 2, half fq & 1
             const int chunk = (nt & 1) * 2 + (fq >> 1);
-            equss::lds_store_b64(xs + (wn * 3 + (nt >> 1)) * 4096 + (wm * 2 + mt) * 1024 + (fr * 4 + (chunk ^ swz4(fr >> 2))) * 16 + (fq & 1) * 8,
+            equss::lds_store_b64(xs + (wn * 3 + (nt >> 1)) * 4096 + (wm * MT + mt) * 1024 + (fr * 4 + (chunk ^ swz4(fr >> 2))) * 16 + (fq & 1) * 8,
                                  lo, hi);
         });
         for (int c = 0; c < NCH; ++c) {
             // ---- G1: h = a W1_c^T (4 steps of 96 = three 32-wide slices), wave tile 32 x 32 -----------------------
-            f32x4 acc1[2][2];
+            f32x4 acc1[2][MT];
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
             for (int kt = 0; kt < G1S; ++kt) {
                 const uint32_t base = next_stage();
                 const uint32_t sa = xs_a + kt * 3 * 4096, sw = base + w32_off;
-                L4 f0[4], f1[4], f2[4];   // two row fragments of a, two of W1 per slice
-#define EQUSS_BW_LOAD(f, sub) \
-                f[0] = LD<sub * 4096>(sa); f[1] = LD<sub * 4096 + 1024>(sa); f[2] = LD<sub * 8192>(sw); f[3] = LD<sub * 8192 + 1024>(sw);
-#define EQUSS_BW_MMS(f)                                              \
+                L4 a0[MT], a1[MT], a2[MT], w0[2], w1[2], w2[2];   // row fragments of a, two of W1, per 32-wide slice
+#define EQUSS_BW_LOAD(a, w, sub) \
+                load_frags<sub * 4096, 1024>(a, sa); w[0] = LD<sub * 8192>(sw); w[1] = LD<sub * 8192 + 1024>(sw);
+#define EQUSS_BW_MMS(a, w)                                           \
                 _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)     \
-                    _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = MM(f[2 + nt], f[mt], acc1[nt][mt]);
-                EQUSS_BW_LOAD(f0, 0)
-                EQUSS_BW_LOAD(f1, 1)
-                EQUSS_BW_LOAD(f2, 2)
+                    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = MM(w[nt], a[mt], acc1[nt][mt]);
+                EQUSS_BW_LOAD(a0, w0, 0)
+                EQUSS_BW_LOAD(a1, w1, 1)
+                EQUSS_BW_LOAD(a2, w2, 2)
                 __builtin_amdgcn_s_setprio(1);
-                equss::lds_wait_for<8>(f0[0], f0[1], f0[2], f0[3]);
-                EQUSS_BW_MMS(f0)
-                equss::lds_wait_for<4>(f1[0], f1[1], f1[2], f1[3]);
-                EQUSS_BW_MMS(f1)
-                equss::lds_wait_for<0>(f2[0], f2[1], f2[2], f2[3]);
-                EQUSS_BW_MMS(f2)
+                wait_frags<2 * (MT + 2)>(a0, w0);
+                EQUSS_BW_MMS(a0, w0)
+                wait_frags<MT + 2>(a1, w1);
+                EQUSS_BW_MMS(a1, w1)
+                wait_frags<0>(a2, w2);
+                EQUSS_BW_MMS(a2, w2)
                 __builtin_amdgcn_s_setprio(0);
 #undef EQUSS_BW_LOAD
 #undef EQUSS_BW_MMS
@@ -356,8 +393,8 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
                     const f32x4 b4 = as_f32x4(b[nt]);
                     const int half = nloc >> 6, n6 = nloc & 63;
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        const int row = wm * 32 + mt * 16 + fr;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int row = wm * RW + mt * 16 + fr;
                         f32x4 v = acc1[nt][mt];
                         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
 #ifndef EQUSS_ABL_BWNOGELU
@@ -379,7 +416,7 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
 #pragma unroll
                 for (int nt = 0; nt < 6; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt) {
                         const f32x4 b4 = as_f32x4(b[nt]);
                         acc2[nt][mt].x += b4.x; acc2[nt][mt].y += b4.y; acc2[nt][mt].z += b4.z; acc2[nt][mt].w += b4.w;
                     }
@@ -394,23 +431,23 @@ __global__ __launch_bounds__(kThreads, 1) void block_ws_kernel(const BwArgs g) {
         }
         // the next tile's residual rows: requested here, under the epilogue (every path defines xn: its old value has
         // been dead since the tile began, and a conditional definition would keep 48 registers alive across the tile)
-        if (t + 1 < my_tiles) request_x(x_start + c_tile + nslots);
+        if (WM == 2 && t + 1 < my_tiles) request_x(x_start + c_tile + nslots);
         else {
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < 6; ++nt) xn[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         // ---- epilogue: x back, LayerNorm of the final rows as bf16 -------------------------------------------------
         row_stats();
         if (g.ln) {
-            u16* lrow = g.ln + (size_t)(m0 + wm * 32 + fr) * g.ld_ln + wn * 96 + fq * 4;
+            u16* lrow = g.ln + (size_t)(m0 + wm * RW + fr) * g.ld_ln + wn * 96 + fq * 4;
             normalise(gamma_s, beta_s, [&](int nt, int mt, uint32_t lo, uint32_t hi) {
                 if (row_ok[mt]) *reinterpret_cast<uint2*>(lrow + (size_t)(mt * 16) * g.ld_ln + nt * 16) = uint2{lo, hi};
             });
         }
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
 #ifndef EQUSS_ABL_BWNOX
@@ -445,11 +482,17 @@ int block_ws(const void* att, int64_t lda0, const void* wp_image, const void* w1
     g.bp = bp; g.gamma2 = gamma2; g.beta2 = beta2; g.b1 = b1; g.b2 = b2;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln;
     g.eps = eps; g.M = M;
-    if (!lds_opt_in(reinterpret_cast<const void*>(block_ws_kernel), kLds))
-        return fail(EQUSS_E_UNSUPPORTED, "block_ws: cannot reserve %d bytes of LDS", kLds);
     const int ntiles = (M + BM - 1) / BM;
     const int grid = ntiles < 256 ? ntiles : 256;
-    hipLaunchKernelGGL(block_ws_kernel, dim3(grid), dim3(kThreads), kLds, s, g);
+    if (g_block_ws == 2) {
+        if (!lds_opt_in(reinterpret_cast<const void*>(block_ws_kernel<1>), kLds))
+            return fail(EQUSS_E_UNSUPPORTED, "block_ws: cannot reserve %d bytes of LDS", kLds);
+        hipLaunchKernelGGL(block_ws_kernel<1>, dim3(grid), dim3((4 + NP) * 64), kLds, s, g);
+    } else {
+        if (!lds_opt_in(reinterpret_cast<const void*>(block_ws_kernel<2>), kLds))
+            return fail(EQUSS_E_UNSUPPORTED, "block_ws: cannot reserve %d bytes of LDS", kLds);
+        hipLaunchKernelGGL(block_ws_kernel<2>, dim3(grid), dim3((8 + NP) * 64), kLds, s, g);
+    }
     return check_launch("block_ws_kernel");
 }
 

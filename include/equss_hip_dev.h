@@ -35,6 +35,7 @@ void equss_dev_fuse_min_tiles(int tiles);
 /* 1 (default): the fused block-tail kernel reads Wp / W1 as ring-stage images written at the start of the forward; 0: row-major. */
 void equss_dev_tail_images(int on);
 /* 1 (default): inside equss_vit_forward the producer / consumer block-tail kernel (64-row tiles, csrc/block_ws.hip);
+ * 2: the same with four consumer waves of 64 rows instead of eight of 32;
  * 0: the eight-wave kernel of equss_block_tail_bf16 on the whole rounds of 128-row tiles + small-tile launches for the rest. */
 void equss_dev_block_ws(int on);
 

@@ -142,11 +142,11 @@ def test_block_tail_kernels_give_equal_bits_inside_the_vit(pkg, native, dev):
         img = torch.randn(batch, 3, 320, 320, device=dev)
         feats = []
         try:
-            for on in (1, 0):
+            for on in (1, 0, 2):   # default (eight consumer waves), the eight-wave kernel, four consumer waves
                 lib.equss_dev_block_ws(ctypes.c_int(on))
                 with torch.no_grad():
                     feats.append(net.get_intermediate_feat(img, n=1)[0][0].clone())
         finally:
             lib.equss_dev_block_ws(ctypes.c_int(1))
         assert torch.isfinite(feats[0]).all()
-        assert torch.equal(feats[0], feats[1])
+        assert torch.equal(feats[0], feats[1]) and torch.equal(feats[0], feats[2])

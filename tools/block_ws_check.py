@@ -12,7 +12,7 @@ net = pkg.featurizer.vit_small(patch_size=8).to(dev).eval()
 img = torch.randn(batch, 3, 320, 320, device=dev)
 lib = nat.load_library()
 outs = {}
-for on in (0, 1, 0, 1):
+for on in (0, 1, 2, 0, 1, 2):
     lib.equss_dev_block_ws(ctypes.c_int(on))
     with torch.no_grad():
         f = net.get_intermediate_feat(img, n=1)[0][0]
@@ -25,5 +25,5 @@ for on in (0, 1, 0, 1):
     print(f"block_ws={on}: {e0.elapsed_time(e1) / 5:.3f} ms per forward, finite {bool(torch.isfinite(f).all())}", flush=True)
     outs.setdefault(on, f.clone())
 lib.equss_dev_block_ws(ctypes.c_int(0))
-d = (outs[0] - outs[1]).abs().max().item()
-print("equal bits:", torch.equal(outs[0], outs[1]), " max |diff|:", d)
+d = max((outs[0] - outs[1]).abs().max().item(), (outs[0] - outs[2]).abs().max().item())
+print("equal bits:", torch.equal(outs[0], outs[1]), torch.equal(outs[0], outs[2]), " max |diff|:", d)
