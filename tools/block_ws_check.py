@@ -5,6 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 pkg = importlib.import_module("expand-and-quantize-for-unsupervised-semantic-segmentation_amd")
 nat = pkg.native
+if os.environ.get("EQUSS_LIB"):
+    nat.LIB_PATH = os.environ["EQUSS_LIB"]
 dev = torch.device("cuda", 0)
 batch = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 torch.manual_seed(0)
