@@ -267,6 +267,10 @@ bool gemm_ws_supports(int M, int N, int K, int epilogue);
 int gemm_ws_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int M, int N,
                  int K, int epilogue, hipStream_t s);
 
+bool gemm_sw_supports(int M, int N, int K, int64_t ldo, int epilogue);
+int gemm_sw_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo, int M, int N,
+                 int epilogue, hipStream_t s);
+
 int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* out, int64_t ldo,
               int M, int N, int K, int epilogue, hipStream_t s) {
     if (!A || !W || !out) return fail(EQUSS_E_NULL, "gemm_bf16: null pointer argument");
@@ -278,12 +282,15 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
         return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
     // (the in-place residual update keeps the small tiles for short M: that is what the trailing-row
     // routes of the fused kernels want)
+    // long M, K = 384, N a multiple of 384, bf16 output: the weights stay in registers (developer variants 4 and 6 keep it off)
+    if (g_variant == 3 && gemm_sw_supports(M, N, K, ldo, epilogue))
+        return gemm_sw_bf16(A, lda, W, ldw, bias, out, ldo, M, N, epilogue, s);
     // long M, N a multiple of 384, bf16 output: the producer / consumer kernel (developer variant 4 keeps it off)
-    if (g_variant == 3 && gemm_ws_supports(M, N, K, epilogue))
+    if ((g_variant == 3 || g_variant == 6) && gemm_ws_supports(M, N, K, epilogue))
         return gemm_ws_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
     // (the large-tile kernel addresses its operand pieces with 32-bit element offsets)
     const bool fits32 = (int64_t)M * lda < (1LL << 32) && (int64_t)N * ldw < (1LL << 32);
-    if ((g_variant == 3 || g_variant == 4) && fits32 && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
+    if ((g_variant == 3 || g_variant == 4 || g_variant == 6) && fits32 && gemm8_supports(N, K, epilogue) && (epilogue != EQUSS_EPI_RESID_F32 || M > 16384))
         return gemm8_bf16(A, lda, W, ldw, bias, out, ldo, M, N, K, epilogue, s);
     GemmArgs g;
     g.A = reinterpret_cast<const u16*>(A); g.lda = lda;

@@ -16,7 +16,8 @@ extern "C" {
 /* 0 (default): screened fp16 search where it applies; 1: exhaustive fp32 search for every shape;
  * 2: as 0, but K = 256 / 512 on the twelve- / six-wave kernels that score every codeword twice instead of keeping the scores. */
 void equss_dev_pq_mode(int mode);
-/* equss_gemm_bf16 instance: 3 (default) large-tile ring kernel where it applies; 0..2 older 128x128 kernels. */
+/* equss_gemm_bf16 instance: 3 (default) stationary-weights / producer-consumer / large-tile ring kernel where each applies;
+   6 the same without the stationary-weights kernel; 4 large-tile ring kernel only; 0..2 older 128x128 kernels. */
 void equss_dev_gemm_variant(int variant);
 /* large-tile GEMM ring: bits 0..2 = stages (2 default, 3, 4), bit 3 = prefer the 256x256 tile. */
 void equss_dev_gemm_stages(int stages);

@@ -332,15 +332,44 @@ def test_producer_consumer_gemm_equals_the_one_role_kernels(epi, shape, native, 
     guard = torch.full((m + 8, n), 7.0, dtype=torch.bfloat16, device=dev)      # rows past M must stay untouched
     ws = native.gemm_bf16(a, w, bias, epi, out=guard[:m])
     outs = []
-    for variant in (4, 0):
+    for variant in (6, 4, 0):   # (6: the default route without the stationary-weights kernel, which takes K = 384)
         lib.equss_dev_gemm_variant(ctypes.c_int(variant))
         try:
             outs.append(native.gemm_bf16(a, w, bias, epi))
         finally:
             lib.equss_dev_gemm_variant(ctypes.c_int(3))
     torch.cuda.synchronize()
-    assert torch.equal(ws, outs[0]) and torch.equal(ws, outs[1])
+    assert torch.equal(ws, outs[0]) and torch.equal(ws, outs[1]) and torch.equal(ws, outs[2])
     assert bool((guard[m:] == 7.0).all())
     ref = a.double() @ w.double().t() + bias.double()
     ref = F.gelu(ref) if epi == 1 else F.relu(ref) if epi == 2 else ref
     assert float((ws.double() - ref).abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("epi", [0, 1, 2])
+@pytest.mark.parametrize("shape", [(16384 + 57, 1152), (102464, 1152), (20000 + 5, 384), (16384 + 1, 768), (51200, 1536)])
+def test_stationary_weights_gemm_equals_the_ring_kernels(epi, shape, native, dev):
+    """K = 384, long M, N a multiple of 384 (qkv, the head's first GEMM): the kernel that keeps a 384-column strip of W
+    in registers for the whole launch gives the bits of the producer / consumer and large-tile kernels; ragged last
+    row block, row counts that leave some workgroups without work, one to four strips, strided output rows."""
+    import ctypes
+    m, n = shape
+    k = 384
+    g = _rng(11 * m + n + epi)
+    a = _bf(torch.from_numpy(g.standard_normal((m, k)).astype(np.float32))).to(dev)
+    w = _bf(torch.from_numpy((g.standard_normal((n, k)) / math.sqrt(k)).astype(np.float32))).to(dev)
+    bias = torch.from_numpy(g.standard_normal(n).astype(np.float32)).to(dev)
+    lib = native.load_library()
+    guard = torch.full((m + 8, n + 8), 7.0, dtype=torch.bfloat16, device=dev)   # rows past M and the padding columns stay untouched
+    sw = native.gemm_bf16(a, w, bias, epi, out=guard[:m, :n])
+    lib.equss_dev_gemm_variant(ctypes.c_int(6))
+    try:
+        ring = native.gemm_bf16(a, w, bias, epi)
+    finally:
+        lib.equss_dev_gemm_variant(ctypes.c_int(3))
+    torch.cuda.synchronize()
+    assert torch.equal(sw, ring)
+    assert bool((guard[m:] == 7.0).all()) and bool((guard[:, n:] == 7.0).all())
+    ref = a.double() @ w.double().t() + bias.double()
+    ref = F.gelu(ref) if epi == 1 else F.relu(ref) if epi == 2 else ref
+    assert float((sw.double() - ref).abs().max()) < 0.05

@@ -14,6 +14,7 @@ CLASS = [("block_ws_kernel", "block_tail"), ("pack_tail_weights", "pack_weights"
          ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"), ("gemm8_kernel<101,", "patch_gemm+pos+ln"),
          ("cls_rows_kernel", "patch_cls_rows"), ("probe_", "probes"), ("confusion_", "confusion"),
          ("layernorm_rowtile_kernel", "layernorm_tail(proj,fc2)"), ("layernorm_kernel", "layernorm"),
+         ("gemm_sw_kernel<0>", "gemm_bf16out"), ("gemm_sw_kernel<1>", "gemm_fc1"), ("gemm_sw_kernel<2>", "head_gemm1"),
          ("gemm_ws_kernel<0,", "gemm_bf16out"), ("gemm_ws_kernel<1,", "gemm_fc1"), ("gemm_ws_kernel<2,", "head_gemm1"),
          ("gemm8_kernel<1,", "gemm_fc1"), ("gemm8_kernel<0,", "gemm_bf16out"), ("gemm8_kernel<2,", "head_gemm1"),
          ("gemm8_kernel<3, 256", "head_gemm2"), ("gemm8_kernel<3, 128", "patch_gemm"),
