@@ -210,7 +210,9 @@ __global__ __launch_bounds__((4 * WM + NP) * 64, 1) void block_ws_kernel(const B
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
 #ifndef EQUSS_ABL_BWNOX
-                xn[nt][mt] = r0 + mt * 16 < g.M ? *reinterpret_cast<const f32x4*>(xr + (size_t)(mt * 16) * g.ldx + nt * 16)
+                // (the residual rows are read and written once per launch and not again before the next block's tail: with
+                // the non-temporal hint they leave the caches to the rows the neighbouring kernels re-read, +1 % end to end)
+                xn[nt][mt] = r0 + mt * 16 < g.M ? __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(xr + (size_t)(mt * 16) * g.ldx + nt * 16))
                                                 : f32x4{0.f, 0.f, 0.f, 0.f};
 #else
                 xn[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -451,7 +453,7 @@ __global__ __launch_bounds__((4 * WM + NP) * 64, 1) void block_ws_kernel(const B
 #pragma unroll
             for (int nt = 0; nt < 6; ++nt)
 #ifndef EQUSS_ABL_BWNOX
-                if (row_ok[mt]) *reinterpret_cast<f32x4*>(xrow + (size_t)(mt * 16) * g.ldx + nt * 16) = acc2[nt][mt];
+                if (row_ok[mt]) __builtin_nontemporal_store(acc2[nt][mt], reinterpret_cast<f32x4*>(xrow + (size_t)(mt * 16) * g.ldx + nt * 16));
 #else
                 asm volatile("" ::"v"(acc2[nt][mt]));
 #endif
