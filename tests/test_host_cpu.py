@@ -223,3 +223,37 @@ def test_code_index_dump_round_trip(pkg, tmp_path):
         z = torch.randint(0, 512, (num_pq, 2, h, w))
         dump.append(z, torch.zeros(2, hh, ww, dtype=torch.long))
     assert np.load(prefix + "_low_index.npy").shape == (2 * h * w, num_pq)
+
+
+def test_no_register_is_used_while_an_lds_read_into_it_is_pending(pkg, tmp_path):
+    """The ring kernels issue their fragment reads as inline-asm ds_read_b128 and wait for them with counted
+    s_waitcnt lgkmcnt(N).  The compiler takes such a read's result for valid from the instruction on and, with all
+    registers in use, may copy the register (to an AccVGPR, to scratch) before the data is there: garbage results, no
+    fault.  tools/lds_hazard_check.py scans the gfx950 assembly of every kernel file that reads LDS this way, per
+    basic block, for any use of a register with a read pending (the scanner itself is checked on a two-line example)."""
+    import importlib.util
+    import subprocess
+    from concurrent.futures import ThreadPoolExecutor
+    spec = importlib.util.spec_from_file_location("lds_hazard_check", os.path.join(ROOT, "tools", "lds_hazard_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    bad = tmp_path / "bad.s"
+    bad.write_text("\tds_read_b128 v[8:11], v1 offset:0\n\tv_accvgpr_write_b32 a3, v11\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v0, v8\n")
+    assert chk.scan(str(bad)) == 1
+    import importlib
+    build = importlib.import_module(pkg.__name__ + ".build")
+    if not os.path.exists(build.HIPCC):
+        pytest.skip("no hipcc here")
+    files = ["block_ws.hip", "mlp_fused.hip", "gemm_ws.hip", "gemm8_bf16.hip", "attention.hip"]
+
+    def flags_of(name):
+        out = tmp_path / (name[:-4] + ".s")
+        cmd = [build.HIPCC] + build.FLAGS + build.FILE_FLAGS.get(name, []) + ["-S", "--cuda-device-only", "-o", str(out),
+                                                                              os.path.join(build.CSRC, name)]
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert res.returncode == 0, res.stdout
+        return chk.scan(str(out))
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        flagged = dict(zip(files, ex.map(flags_of, files)))
+    assert flagged == {f: 0 for f in files}
