@@ -280,6 +280,9 @@ int gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const floa
     if (lda < K || ldw < K || ldo < N || (lda % 8) || (ldw % 8) || (ldo % 4) || ((uintptr_t)A % 16) ||
         ((uintptr_t)W % 16) || ((uintptr_t)out % 16) || (bias && ((uintptr_t)bias % 16)))
         return fail(EQUSS_E_ALIGN, "gemm_bf16: operands must be 16-byte aligned, lda/ldw multiples of 8, ldo of 4");
+    // (bf16 output rows go out in 16-byte pieces: eight elements)
+    if ((epilogue == EQUSS_EPI_BF16 || epilogue == EQUSS_EPI_GELU_BF16 || epilogue == EQUSS_EPI_RELU_BF16) && (ldo % 8))
+        return fail(EQUSS_E_ALIGN, "gemm_bf16: ldo=%lld must be a multiple of 8 for a bf16 output", (long long)ldo);
     // (the in-place residual update keeps the small tiles for short M: that is what the trailing-row
     // routes of the fused kernels want)
     // long M, K = 384, N a multiple of 384, bf16 output: the weights stay in registers (developer variants 4 and 6 keep it off)

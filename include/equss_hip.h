@@ -151,7 +151,8 @@ int equss_layernorm_bf16(const float* x, int64_t ld_x, const float* gamma, const
  * (nn.Linear / 1x1 nn.Conv2d: vision_transformer.py:81,:89,:59,:62; dino_pqgo.py:104-112,:127-128).
  *   A (M, K) bf16, leading dimension lda;  W (N, K) bf16 (PyTorch [out, in] layout), ldw;
  *   bias (N) fp32 or NULL;  out (M, N) bf16 or fp32 by epilogue, leading dimension ldo.
- * Requires N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0, 16-byte aligned A/W. */
+ * Requires N % 128 == 0, K % 64 == 0, lda/ldw % 8 == 0, ldo % 4 == 0 (% 8 for a bf16 output: rows are
+ * written in 16-byte pieces), 16-byte aligned A/W/out. */
 int equss_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                     void* out, int64_t ldo, int M, int N, int K, int epilogue, void* stream);
 

@@ -373,3 +373,17 @@ def test_stationary_weights_gemm_equals_the_ring_kernels(epi, shape, native, dev
     ref = a.double() @ w.double().t() + bias.double()
     ref = F.gelu(ref) if epi == 1 else F.relu(ref) if epi == 2 else ref
     assert float((sw.double() - ref).abs().max()) < 0.05
+
+
+def test_gemm_rejects_a_bf16_output_stride_that_breaks_16_byte_rows(native, dev):
+    """bf16 output rows go out in 16-byte pieces: a leading dimension that is a multiple of 4 but not of 8 is refused
+    (it is fine for an fp32 output)."""
+    a = torch.zeros((256, 64), dtype=torch.bfloat16, device=dev)
+    w = torch.zeros((128, 64), dtype=torch.bfloat16, device=dev)
+    out = torch.zeros((256, 132), dtype=torch.bfloat16, device=dev)
+    with pytest.raises(ValueError, match="multiple of 8"):
+        native.gemm_bf16(a, w, None, 0, out=out[:, :128])
+    out32 = torch.zeros((256, 132), dtype=torch.float32, device=dev)
+    native.gemm_bf16(a, w, None, 3, out=out32[:, :128])
+    torch.cuda.synchronize()
+    assert float(out32.abs().max()) == 0.0
