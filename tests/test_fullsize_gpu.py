@@ -150,3 +150,23 @@ def test_block_tail_kernels_give_equal_bits_inside_the_vit(pkg, native, dev):
             lib.equss_dev_block_ws(ctypes.c_int(1))
         assert torch.isfinite(feats[0]).all()
         assert torch.equal(feats[0], feats[1]) and torch.equal(feats[0], feats[2])
+
+
+def test_stationary_weights_gemm_gives_equal_bits_inside_the_vit(pkg, native, dev):
+    """qkv of every block (and, at these row counts, nothing else) goes through the stationary-weights GEMM by default:
+    the features equal those of the producer / consumer route bit for bit, at a row count with a ragged last row block."""
+    import ctypes
+    lib = native.load_library()
+    torch.manual_seed(5)
+    net = pkg.featurizer.vit_small(patch_size=8).to(dev).eval()
+    img = torch.randn(37, 3, 320, 320, device=dev)
+    feats = []
+    try:
+        for variant in (3, 6):
+            lib.equss_dev_gemm_variant(ctypes.c_int(variant))
+            with torch.no_grad():
+                feats.append(net.get_intermediate_feat(img, n=1)[0][0].clone())
+    finally:
+        lib.equss_dev_gemm_variant(ctypes.c_int(3))
+    assert torch.isfinite(feats[0]).all()
+    assert torch.equal(feats[0], feats[1])
