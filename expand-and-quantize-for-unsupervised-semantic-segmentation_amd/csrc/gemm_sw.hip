@@ -9,8 +9,8 @@
 // tiles ahead in registers and one ahead in LDS, one workgroup barrier per tile (LDS traffic only).  A fragment read feeds
 // three MFMAs of each wave.  Everything is plain C++ (compiler-placed waits): no LDS-DMA, so no counted waits to get wrong.
 //
-// The k strips of a row block are taken by k workgroups of the same XCD at the same time, so the block comes from HBM once
-// and from that XCD's L2 otherwise; 32 workgroups per XCD = 10 groups of 3 strips + 2 idle for qkv (6 %).
+// The k strips of a row block are taken by k workgroups at about the same time (any XCD: the block comes from HBM once and
+// from the memory-side cache otherwise).
 // Same operand rounding and fp32 operation order as gemm_ws_kernel / gemm8_kernel (accumulate from zero over ascending
 // 32-wide k slices, then bias, then the activation): equal bits.
 #include "equss_common.h"
@@ -53,14 +53,16 @@ __global__ __launch_bounds__(kThreads, 1) void gemm_sw_kernel(const SwArgs g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 15, fq = lane >> 4;
 
-    // row blocks of this workgroup: the XCD's contiguous range, dealt round robin to its groups of ntn workgroups
+    // Strip bid % ntn, and among the workgroups of that strip the row blocks dealt round robin: every workgroup of the launch
+    // has work, a row block is read by its ntn workgroups at about the same time, and the launch sweeps the rows as one
+    // window.  (Keeping the strips of a row block on one XCD, for its L2, with a range of rows per XCD: 10 % slower, and 2 of
+    // an XCD's 32 workgroups idle when ntn = 3; a contiguous range of row blocks per workgroup: 18 % slower.)
     const int nrb = (g.M + BM - 1) / BM;
-    const int bid = blockIdx.x, xcd = bid & 7, j = bid >> 3;
-    const int groups = (int)(gridDim.x >> 3) / g.ntn, group = j / g.ntn, strip = j % g.ntn;
-    const int q8 = nrb >> 3, r8 = nrb & 7;
-    const int x_start = xcd * q8 + (xcd < r8 ? xcd : r8);
-    const int x_len = q8 + (xcd < r8 ? 1 : 0);
-    if (group >= groups || group >= x_len) return;
+    const int bid = blockIdx.x;
+    const int strip = bid % g.ntn, group = bid / g.ntn;
+    const int groups = ((int)gridDim.x - strip + g.ntn - 1) / g.ntn;   // workgroups of this strip
+    const int x_start = 0, x_len = nrb;
+    if (group >= x_len) return;
     const int my_n = (x_len - group + groups - 1) / groups;
 
     // ---- this wave's 48 columns of W and of the bias, for the whole launch ------------------------------------------------
