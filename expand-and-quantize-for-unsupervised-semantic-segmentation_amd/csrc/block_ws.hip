@@ -469,6 +469,7 @@ extern "C" void equss_dev_block_ws(int on) { g_block_ws = on; }  // tuning knob,
 namespace equss {
 
 bool block_ws_enabled() { return g_block_ws != 0; }
+int block_ws_mode() { return g_block_ws; }
 
 // All three weight matrices as stage images (pack_tail_weights: Wp, W1, and W2 in 32-wide slices).
 int block_ws(const void* att, int64_t lda0, const void* wp_image, const void* w1_image, const void* w2_image, const float* bp,

@@ -594,7 +594,7 @@ __global__ __launch_bounds__(kThreads, 2) void mlp_kernel(const MlpArgs g) {
 //   w2t: [chunk 0..11][step 0..3][piece 0..23][64 lanes][8]  <- W2 rows piece*16 + lane/4, columns chunk*128 + step*32 + chunk*8
 //        (32-wide slices of W2: what block_ws.hip stages; mlp_kernel reads W2 row-major in 64-wide slices)
 constexpr int kWptUnits = G0S * 24 * 64, kW1tUnits = NCH * G1S * 3 * 8 * 64, kW2tUnits = NCH * 4 * 24 * 64;
-struct PackArgs { const u16* wp[16]; const u16* w1[16]; const u16* w2[16]; u16* out; };
+struct PackArgs { const u16* wp[16]; const u16* w1[16]; const u16* w2[16]; u16* out; size_t stride; };   // stride: elements between blocks
 __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const PackArgs a) {
     const int blk = blockIdx.y;
     const int u = blockIdx.x * 256 + threadIdx.x;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const PackArgs a
         const int v = (u - kWptUnits - kW1tUnits) >> 6, piece = v % 24, step = (v / 24) & 3, ch = v / 96;
         src = a.w2[blk] + (size_t)(piece * 16 + row16) * HID + ch * HC + step * 32 + chunk;
     }
-    u16* dst = a.out + (size_t)blk * (kWptUnits + kW1tUnits + kW2tUnits) * 8 + (size_t)u * 8;
+    u16* dst = a.out + (size_t)blk * a.stride + (size_t)u * 8;
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 }
 
@@ -620,11 +620,11 @@ __global__ __launch_bounds__(256) void pack_tail_weights_kernel(const PackArgs a
 namespace equss {
 
 // Bytes of the stage images of one block's projection + fc1 + fc2 weights, and the launch that writes them for `depth`
-// blocks (depth <= 16) into out[depth][tail_weight_image_bytes()]: the Wp image, then the W1 image, then the W2 image.
+// blocks (depth <= 16), block i at out + i * stride bytes: the Wp image, then the W1 image, then the W2 image.
 size_t tail_weight_image_bytes() { return (size_t)(kWptUnits + kW1tUnits + kW2tUnits) * 16; }
 size_t tail_weight_wp_bytes() { return (size_t)kWptUnits * 16; }
 size_t tail_weight_w1_bytes() { return (size_t)kW1tUnits * 16; }
-int pack_tail_weights(const void* const* wp, const void* const* w1, const void* const* w2, int depth, void* out, hipStream_t s) {
+int pack_tail_weights(const void* const* wp, const void* const* w1, const void* const* w2, int depth, void* out, size_t stride, hipStream_t s) {
     if (depth < 1 || depth > 16) return fail(EQUSS_E_UNSUPPORTED, "pack_tail_weights: depth=%d (1..16)", depth);
     PackArgs a;
     for (int i = 0; i < depth; ++i) {
@@ -634,7 +634,7 @@ int pack_tail_weights(const void* const* wp, const void* const* w1, const void* 
         a.w1[i] = reinterpret_cast<const u16*>(w1[i]);
         a.w2[i] = reinterpret_cast<const u16*>(w2[i]);
     }
-    a.out = reinterpret_cast<u16*>(out);
+    a.out = reinterpret_cast<u16*>(out); a.stride = stride / 2;   // (bytes between blocks, >= tail_weight_image_bytes())
     hipLaunchKernelGGL(pack_tail_weights_kernel, dim3((kWptUnits + kW1tUnits + kW2tUnits + 255) / 256, depth), dim3(256), 0, s, a);
     return check_launch("pack_tail_weights_kernel");
 }

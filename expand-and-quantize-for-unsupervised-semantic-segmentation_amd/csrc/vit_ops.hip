@@ -17,8 +17,14 @@ int block_fused(const void* att, int64_t lda0, const void* wp, const float* bp, 
 size_t tail_weight_image_bytes();
 size_t tail_weight_wp_bytes();
 size_t tail_weight_w1_bytes();
-int pack_tail_weights(const void* const* wp, const void* const* w1, const void* const* w2, int depth, void* out, hipStream_t s);
+int pack_tail_weights(const void* const* wp, const void* const* w1, const void* const* w2, int depth, void* out, size_t stride, hipStream_t s);
 bool block_ws_enabled();
+int block_ws_mode();
+size_t rs_weight_image_bytes();
+int pack_rs_weights(const void* const* wp, const void* const* w1, const void* const* w2, int depth, void* out, size_t stride, hipStream_t s);
+int block_rs(const void* att, int64_t lda0, const void* image, const float* bp, const float* gamma2, const float* beta2,
+             const float* b1, const float* b2, float* x, int64_t ldx, const float* gamma, const float* beta, void* ln,
+             int64_t ld_ln, int M, float eps, hipStream_t s);
 int block_ws(const void* att, int64_t lda0, const void* wp_image, const void* w1_image, const void* w2_image, const float* bp,
              const float* gamma2, const float* beta2, const float* b1, const float* b2, float* x, int64_t ldx, const float* gamma,
              const float* beta, void* ln, int64_t ld_ln, int M, float eps, hipStream_t s);
@@ -159,6 +165,12 @@ PatchWs carve_patch(void* ws, int B, int H, int W, int P, int C) {
     return w;
 }
 
+// bytes between the weight images of two blocks (either block-tail kernel's format fits)
+size_t tail_image_stride() {
+    const size_t a = equss::tail_weight_image_bytes(), b = equss::rs_weight_image_bytes();
+    return align256(a > b ? a : b);
+}
+
 struct VitWs { float* x; u16* ln; u16* qkv; u16* att; u16* hid; void* patch; size_t patch_bytes; char* wimg; size_t bytes; };
 // wimg: ring-stage images of every block's projection + fc1 weights for the fused block-tail kernel (C = 384, up to 16
 // blocks: 1.4 MiB each, rewritten by every forward: the weights may have changed between two calls)
@@ -179,7 +191,7 @@ VitWs carve_vit(void* ws, int C, int B, int H, int W, int P, int depth) {
     w.wimg = nullptr;
     if (equss::mlp_fused_supports(C, 4 * C) && depth >= 1 && depth <= 16) {
         w.wimg = base + off;
-        off += align256(equss::tail_weight_image_bytes()) * depth;
+        off += tail_image_stride() * depth;
     }
     w.bytes = off;
     return w;
@@ -321,7 +333,9 @@ int block_balanced(const void* att, const void* wp, const float* bp, const float
     int rc;
     {
         equss::ProfScope ps(EQUSS_K_BLOCK_TAIL, s);   // the fused launch alone; the trailing rows count under the GEMM classes
-        if (ws)
+        if (ws && equss::block_ws_mode() == 3)
+            rc = equss::block_rs(att, C, wimg, bp, gamma2, beta2, b1, b2, x, C, gamma, beta, ln, C, m_main, eps, s);
+        else if (ws)
             rc = equss::block_ws(att, C, wimg, wimg + equss::tail_weight_wp_bytes(),
                                  wimg + equss::tail_weight_wp_bytes() + equss::tail_weight_w1_bytes(), bp, gamma2, beta2, b1, b2, x, C,
                                  gamma, beta, ln, C, m_main, eps, s);
@@ -480,7 +494,8 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
         const void* wp[16]; const void* w1[16]; const void* w2[16];
         for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; w2[i] = vit->blocks[i].fc2_w; }
         equss::ProfScope ps(EQUSS_K_GEMM_PROJ, s);
-        rc = equss::pack_tail_weights(wp, w1, w2, vit->depth, w.wimg, s);
+        rc = equss::block_ws_mode() == 3 ? equss::pack_rs_weights(wp, w1, w2, vit->depth, w.wimg, tail_image_stride(), s)
+                                         : equss::pack_tail_weights(wp, w1, w2, vit->depth, w.wimg, tail_image_stride(), s);
         if (rc) return rc;
         images = true;
     }
@@ -508,7 +523,7 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
         if (fuse && big && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
             return block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s,
-                                  images ? w.wimg + (size_t)i * align256(equss::tail_weight_image_bytes()) : nullptr);
+                                  images ? w.wimg + (size_t)i * tail_image_stride() : nullptr);
         }
         if (fuse) {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, resid_ln_balanced(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
