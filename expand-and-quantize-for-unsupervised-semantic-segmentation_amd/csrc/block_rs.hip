@@ -32,12 +32,13 @@ struct RsArgs {
     u16* ln; int64_t ld_ln;                            // LayerNorm(x) for the next consumer (may be null)
     float eps;
     int M;
+    int stagger;
 };
 
 constexpr int C = 384, HID = 1536, HC = 256, NCH = HID / HC;
 constexpr int NW = 8, WN = C / NW, NT = WN / 16, NT1 = HC / NW / 16;   // 48 columns = 3 fragments; 32 hidden units = 2
 constexpr int KS = C / 32, KS2 = HC / 32;                              // 12 k slices of C, 8 of a hidden chunk
-constexpr int NGMAX = 7;
+constexpr int NGMAX = 7, RGMIN = 4;   // row groups of 16 in a tile: at most 7; a tile of fewer than 4 still pays for 4
 constexpr int PD = 4, GW = 3;                                          // weight groups in flight, fragments per group
 constexpr int kGroupsChunk = (KS * NT1 + KS2 * NT) / GW;               // 8 of W1 + 8 of W2
 constexpr int kGroupsTile = KS * NT / GW + NCH * kGroupsChunk;         // 12 + 96
@@ -53,6 +54,19 @@ static_assert((KS * NT) % GW == 0 && (KS * NT1) % GW == 0 && (KS * NT / GW) % PD
               "ring slots must be compile-time constants");
 
 typedef equss::lds_u32x4 L4;
+// Developer build (-DEQUSS_ABL_RSSTAMPS): the shader clock at every phase boundary of every wave of one workgroup, kept in the
+// spare LDS and copied out at the end (tools/rs_stamps.py); the product build contains none of it.
+#ifdef EQUSS_ABL_RSSTAMPS
+constexpr int kStampMax = 160, kStampWg = 77;
+__device__ uint32_t g_rs_stamps[NW * kStampMax];
+#define RS_STAMP()                                                                                                        \
+    do {                                                                                                                  \
+        if (g.ln && blockIdx.x == kStampWg && (threadIdx.x & 63) == 0 && *stamp_n < kStampMax)                                \
+            reinterpret_cast<uint32_t*>(smem + kLds)[(threadIdx.x >> 6) * kStampMax + (*stamp_n)++] = (uint32_t)__builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define RS_STAMP() do {} while (0)
+#endif
 __device__ __forceinline__ f32x4 MM(const L4& w, const L4& a, f32x4 c) {
 #ifndef EQUSS_ABL_RSNOMFMA   // (EQUSS_ABL_*: developer builds that leave one cost out; wrong results by design)
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
@@ -78,14 +92,95 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rows_rsrc(const void* p, int64
                                              __builtin_amdgcn_readfirstlane(nrows * (int)ld_bytes), 0x00020000);
 }
 
-// One tile of NG 16-row groups: rows [row0, row0 + nrows), nrows <= 16 NG.  wr is the wave's ring of weight groups
+// Requests for the rows of a tile, shared by the kernel's prologue and by the tile body (which asks for the NEXT tile's
+// rows before it stores its own: vector-memory operations retire in issue order, so loads issued behind a tile's stores
+// would wait for those stores to reach memory).
+constexpr int kAttPieces = (NGMAX * KS + NW - 1) / NW;   // 1-KiB fragments of the attention tile a wave stages
+constexpr int kAttHalf = (kAttPieces + 1) / 2;              // ... in two halves: pieces [0, kAttHalf) and [kAttHalf, kAttPieces)
+template <int RG_LO = 0, int RG_HI = NGMAX>
+__device__ __forceinline__ void request_x(const RsArgs& g, f32x4 (&xr)[NGMAX][NT], int row0, int nrows, int l_, int wave) {
+    const __amdgpu_buffer_rsrc_t x_rs = rows_rsrc(g.x, g.ldx * 4, row0, nrows);
+    const uint32_t x_rg = 64u * (uint32_t)g.ldx;
+    const uint32_t x_lane = (uint32_t)((l_ & 15) * (int)g.ldx + wave * WN + (l_ >> 4) * 4) * 4u;
+#pragma unroll
+    for (int rg = RG_LO; rg < RG_HI; ++rg)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#if !defined(EQUSS_ABL_RSNOX) && !defined(EQUSS_ABL_RSNOLD)
+            // (read and written once per launch and not again before the next block's tail: non-temporal)
+            xr[rg][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, x_lane + nt * 64, rg * x_rg, 2));
+#else
+            xr[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
+}
+// attention rows global -> registers (rows past the end read as zeros; their outputs are not stored) ...
+template <int HALF>
+__device__ __forceinline__ void request_att(const RsArgs& g, L4 (&pre)[kAttHalf], int row0, int nrows, int l_, int wave) {
+    const __amdgpu_buffer_rsrc_t a_rs = rows_rsrc(g.A0, g.lda0 * 2, row0, nrows);
+    const uint32_t a_lane = (uint32_t)((l_ & 15) * (int)g.lda0 + (l_ >> 4) * 8) * 2u;
+#pragma unroll
+    for (int i = HALF * kAttHalf; i < (HALF ? kAttPieces : kAttHalf); ++i) {
+        int f = wave + NW * i;
+        f = f < NGMAX * KS ? f : NGMAX * KS - 1;   // (the last few waves repeat the last fragment: same bytes to the same place)
+        const int rg = f / KS, s = f % KS;
+        pre[i - HALF * kAttHalf] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_lane, (uint32_t)(rg * 16 * (int)g.lda0 + s * 32) * 2u, 0);
+    }
+}
+// ... -> LDS in fragment order (lane l at byte 16 l of fragment (k slice s, row group rg))
+template <int HALF>
+__device__ __forceinline__ void stage_att(char* xs, const L4 (&pre)[kAttHalf], int l_, int wave) {
+#pragma unroll
+    for (int i = HALF * kAttHalf; i < (HALF ? kAttPieces : kAttHalf); ++i) {
+        int f = wave + NW * i;
+        f = f < NGMAX * KS ? f : NGMAX * KS - 1;
+        const int rg = f / KS, s = f % KS;
+        *reinterpret_cast<L4*>(xs + (s * NGMAX + rg) * 1024 + l_ * 16) = pre[i - HALF * kAttHalf];
+    }
+}
+
+// the same rows global -> LDS without passing registers (LDS-DMA: lane l of a wave instruction lands at byte 16 l of its 1-KiB
+// destination, which is the fragment order)
+__device__ __forceinline__ void dma_att(const RsArgs& g, char* xs, int row0, int nrows, int l_, int wave) {
+    const __amdgpu_buffer_rsrc_t a_rs = rows_rsrc(g.A0, g.lda0 * 2, row0, nrows);
+    const uint32_t a_lane = (uint32_t)((l_ & 15) * (int)g.lda0 + (l_ >> 4) * 8) * 2u;
+#pragma unroll
+    for (int i = 0; i < kAttPieces; ++i) {
+        int f = wave + NW * i;
+        f = f < NGMAX * KS ? f : NGMAX * KS - 1;
+        const int rg = f / KS, s = f % KS;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(a_rs, (__attribute__((address_space(3))) void*)(xs + (s * NGMAX + rg) * 1024), 16, a_lane,
+                                                 (uint32_t)(rg * 16 * (int)g.lda0 + s * 32) * 2u, 0, 0);
+    }
+}
+
+// One tile of ng <= NGMAX 16-row groups: rows [row0, row0 + nrows), nrows <= 16 ng.  wr is the wave's ring of weight groups
 // (on entry groups 0 .. PD-1 of the stream are in it or on their way; the same holds on exit), w_rs the wave's stream.
-template <int NG>
-__device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD][GW], const __amdgpu_buffer_rsrc_t w_rs, int row0,
-                                        int nrows, int lane, int wave) {
+// On entry xr holds (or is about to receive) the tile's residual rows and xs its attention rows, staged but not yet
+// published by a barrier; on exit the same holds for the next tile, rows [next_row0, next_row0 + next_nrows).
+__device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD][GW], const __amdgpu_buffer_rsrc_t w_rs, f32x4 (&xr)[NGMAX][NT], int ng,
+                                        int row0, int nrows, int next_row0, int next_nrows, int lane, int wave, int* stamp_n) {
     // fragment number `frag` of the wave's stream (plus a scalar byte offset): one lane-offset register, no 64-bit addresses
-    auto wload = [&](int frag, uint32_t sbase) { return __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, sbase + frag * 1024, 0); };
-    const int fr = lane & 15, fq = lane >> 4;
+    // One body for every tile height: row groups RGMIN .. NGMAX - 1 are skipped group by group (wave-uniform branches) when
+    // the tile is shorter.  (One instantiation per height in one kernel costs registers at every join: spilled weight
+    // fragments; one kernel per height costs a launch per height.)
+    constexpr int NG = NGMAX;
+    // Lane numbers the compiler cannot see through: every phase recomputes its lane offsets from one (a few integer
+    // instructions) instead of keeping them in registers across the tile, where they do not fit beside the accumulators: a
+    // reload of a spilled register is a vector-memory load whose wait drains the weight requests in flight.
+    // (v_mbcnt gives the lane number out of nothing, so not even `lane` has to stay in a register for them)
+    // (inside the asm statement: as a builtin it is hoisted out of the tile loop like any other invariant, and spilled)
+    auto olane = [&]() {
+        int l;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+        return l;
+    };
+    const int lane16 = olane() * 16;   // (per tile: nothing derived from the lane number lives across tiles)
+    auto active = [&](int rg) { return rg < RGMIN || rg < ng; };
+#ifndef EQUSS_ABL_RSNOW
+    auto wload = [&](int frag, uint32_t sbase) { return __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane16, sbase + frag * 1024, 0); };
+#else
+    auto wload = [&](int frag, uint32_t sbase) { return L4{(uint32_t)frag, sbase, 0u, 0u}; };
+#endif
     char* const xs = smem;
     char* const hs = smem + kOffHs;
     const float* const b1_s = reinterpret_cast<const float*>(smem + kOffPar);
@@ -95,73 +190,71 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
     const float* const bp_s = beta_s + C;
     const float* const gamma2_s = bp_s + C;
     const float* const beta2_s = gamma2_s + C;
-    const int col0 = wave * WN + fq * 4;   // this lane's four columns of column group nt: col0 + 16 nt ..+ 3
+    // (col0 = wave * WN + fq * 4 below: this lane's four columns of column group nt are col0 + 16 nt ..+ 3)
 
-    // ---- residual rows straight into the accumulators; attention rows global -> registers -> LDS (fragment order) ----
+    RS_STAMP();   // tile begins
     const __amdgpu_buffer_rsrc_t x_rs = rows_rsrc(g.x, g.ldx * 4, row0, nrows);
-    const uint32_t x_lane = (uint32_t)(fr * (int)g.ldx + col0) * 4u;
     const uint32_t x_rg = 64u * (uint32_t)g.ldx;   // bytes from one 16-row group to the next
     f32x4 acc2[NG][NT];   // rows rg*16 + fr, columns col0 + nt*16 + 0..3
-#pragma unroll
-    for (int rg = 0; rg < NG; ++rg)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#ifndef EQUSS_ABL_RSNOX
-            // (read and written once per launch and not again before the next block's tail: non-temporal)
-            acc2[rg][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(x_rs, x_lane + nt * 64, rg * x_rg, 2));
-#else
-            acc2[rg][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
     {
-        constexpr int NF = NG * KS, PF = (NF + NW - 1) / NW;
-        // (rows past the end read as zeros; their outputs are not stored)
-        const __amdgpu_buffer_rsrc_t a_rs = rows_rsrc(g.A0, g.lda0 * 2, row0, nrows);
-        const uint32_t a_lane = (uint32_t)(fr * (int)g.lda0 + fq * 8) * 2u;
-        L4 pre[PF];
+        const int l_ = olane(), col0 = wave * WN + (l_ >> 4) * 4;
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int f = wave + NW * i;
-            f = f < NF ? f : NF - 1;   // (the last few waves repeat the last fragment: same bytes to the same place)
-            const int rg = f / KS, s = f % KS;
-            pre[i] = __builtin_amdgcn_raw_buffer_load_b128(a_rs, a_lane, (uint32_t)(rg * 16 * (int)g.lda0 + s * 32) * 2u, 0);
+        for (int nt = 0; nt < NT; ++nt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(bp_s + col0 + nt * 16);
+#pragma unroll
+            for (int rg = 0; rg < NG; ++rg) { acc2[rg][nt] = xr[rg][nt]; add4(acc2[rg][nt], b); }
         }
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int f = wave + NW * i;
-            f = f < NF ? f : NF - 1;
-            const int rg = f / KS, s = f % KS;
-            *reinterpret_cast<L4*>(xs + (s * NGMAX + rg) * 1024 + lane * 16) = pre[i];
-        }
-    }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bp_s + col0 + nt * 16);
-#pragma unroll
-        for (int rg = 0; rg < NG; ++rg) add4(acc2[rg][nt], b);
     }
     lds_barrier();
+    RS_STAMP();   // rows staged
 
+    // The MFMA loops are written in issue order and pinned there (sched_barrier): per row group the MFMAs of k slice s, then
+    // that group's A fragment of slice s + 1 into the registers just read, so that a fragment read has the MFMAs of the
+    // other NG - 1 groups to land; the weight group PD further on is requested into the ring slot the slice has used up.
+    // (Left to itself the scheduler sinks the weight requests to just before their use and waits for every fragment read
+    // right after issuing it.)
+#define RS_PIN() __builtin_amdgcn_sched_barrier(0)
+    L4 a[NG];
+    // Fragment reads through three 32-bit LDS addresses (lane offset included) that the compiler cannot fold constants
+    // into: k slices 0 .. 5 and 6 .. 11 of xs and the hidden tile, each with 16-bit immediate offsets.  (From one base it
+    // materialises a register for every fragment beyond the first 64 KiB and keeps all of them across the tile.)
+    typedef const __attribute__((address_space(3))) L4* LdsFrag;
+    uint32_t xa_lo = equss::lds_addr(xs) + lane16, xa_hi = xa_lo + (KS / 2) * NGMAX * 1024, ha = equss::lds_addr(hs) + lane16;
+    asm volatile("" : "+v"(xa_lo), "+v"(xa_hi), "+v"(ha));
+#ifndef EQUSS_ABL_RSNOLDS
+    auto rd = [](uint32_t base, int off) { return *reinterpret_cast<LdsFrag>(base + off); };
+#else
+    auto rd = [](uint32_t base, int off) { L4 v; asm volatile("" : "=v"(v) : "v"(base), "s"(off)); return v; };
+#endif
+    auto frag_x = [&](int s, int rg) { return s < KS / 2 ? rd(xa_lo, (s * NGMAX + rg) * 1024) : rd(xa_hi, ((s - KS / 2) * NGMAX + rg) * 1024); };
+    auto frag_h = [&](int s, int rg) { return rd(ha, (s * NGMAX + rg) * 1024); };
     // ---- G0: acc2 = x + bp + att Wp^T (12 k slices; stream groups 0 .. 11) ---------------------------------------------
 #pragma unroll
+    for (int rg = 0; rg < NG; ++rg) a[rg] = frag_x(0, rg);
+    RS_PIN();
+#pragma unroll
     for (int s = 0; s < KS; ++s) {
-        L4 a[NG];
 #pragma unroll
-        for (int rg = 0; rg < NG; ++rg) a[rg] = *reinterpret_cast<const L4*>(xs + (s * NGMAX + rg) * 1024 + lane * 16);
+        for (int rg = 0; rg < NG; ++rg) {
+            if (active(rg)) {
 #pragma unroll
-        for (int rg = 0; rg < NG; ++rg)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc2[rg][nt] = MM(wr[s % PD][nt], a[rg], acc2[rg][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc2[rg][nt] = MM(wr[s % PD][nt], a[rg], acc2[rg][nt]);
+                if (s + 1 < KS) a[rg] = frag_x(s + 1, rg);
+            }
+            RS_PIN();
+        }
 #pragma unroll
         for (int e = 0; e < GW; ++e) wr[s % PD][e] = wload((s + PD) * GW + e, 0);
+        RS_PIN();
     }
 
+    RS_STAMP();   // G0 done
     // LayerNorm of the rows in acc2 with scale / shift at gs / bs: fn(rg, nt, lo, hi) gets four bf16 as two dwords.
     // Per row the sums run over the column groups in the order of the 96-column layout (see the header).
-    auto layer_norm = [&](const float* gs, const float* bs, auto&& fn) {
+    auto layer_norm = [&](const float* gs, const float* bs, auto&& mid, auto&& fn, auto&& after_group) {
         // (lane numbers the compiler cannot see through: the scratch addresses are recomputed here, a few integer
         // instructions, instead of living in registers across the tile, where they would not fit beside the accumulators)
-        int lo_ = lane;
-        asm volatile("" : "+v"(lo_));
+        const int lo_ = olane();
         const int fr = lo_ & 15, fq = lo_ >> 4, col0 = wave * WN + fq * 4;
         float2* const P = reinterpret_cast<float2*>(hs + kStatP);
         float2* const S = reinterpret_cast<float2*>(hs + kStatS);
@@ -177,60 +270,74 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
         if (!(wave & 1)) {
 #pragma unroll
             for (int rg = 0; rg < NG; ++rg) {
+                if (!active(rg)) continue;
                 float s1 = 0.f, s2 = 0.f;
                 chain(rg, s1, s2);
                 P[(pair * 4 + fq) * (NGMAX * 16) + rg * 16 + fr] = make_float2(s1, s2);
             }
         }
+        RS_STAMP();   // (LayerNorm: first half of the sums)
         lds_barrier();
+        RS_STAMP();
         if (wave & 1) {
 #pragma unroll
             for (int rg = 0; rg < NG; ++rg) {
+                if (!active(rg)) continue;
                 const float2 p = P[(pair * 4 + fq) * (NGMAX * 16) + rg * 16 + fr];
                 float s1 = p.x, s2 = p.y;
                 chain(rg, s1, s2);
-                s1 += __shfl_xor(s1, 16, 64); s2 += __shfl_xor(s2, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64); s2 += __shfl_xor(s2, 32, 64);
+                // (__shfl_xor with its lane addresses built here: hoisted out of the tile loop they get spilled)
+                auto other = [&](float v, int mask) {
+                    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lo_ ^ mask) << 2, __builtin_bit_cast(int, v)));
+                };
+                s1 += other(s1, 16); s2 += other(s2, 16);
+                s1 += other(s1, 32); s2 += other(s2, 32);
                 if (fq == 0) S[(rg * 16 + fr) * 4 + pair] = make_float2(s1, s2);
             }
         }
+        RS_STAMP();   // (LayerNorm: second half of the sums)
         lds_barrier();
-        float mean[NG], rstd[NG];
+        RS_STAMP();
+        mid();
+        // (row group by row group, scale and shift read again for each: seven means and seven scales kept across the loop
+        // would not fit beside the accumulators and the next tile's rows)
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) {
+            if (!active(rg)) continue;
             const f32x4 q0 = *reinterpret_cast<const f32x4*>(S + (rg * 16 + fr) * 4);
             const f32x4 q1 = *reinterpret_cast<const f32x4*>(S + (rg * 16 + fr) * 4 + 2);
-            mean[rg] = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
+            const float mean = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
             const float ex2 = ((q0.y + q0.w) + (q1.y + q1.w)) * (1.0f / C);
-            rstd[rg] = 1.0f / sqrtf(fmaxf(fmaf(-mean[rg], mean[rg], ex2), 0.f) + g.eps);
-        }
+            const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + col0 + nt * 16);
-            const f32x4 be = *reinterpret_cast<const f32x4*>(bs + col0 + nt * 16);
-#pragma unroll
-            for (int rg = 0; rg < NG; ++rg) {
+            for (int nt = 0; nt < NT; ++nt) {
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + col0 + nt * 16);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(bs + col0 + nt * 16);
                 const f32x4 v = acc2[rg][nt];
-                fn(rg, nt, equss::pack_bf16(fmaf((v.x - mean[rg]) * rstd[rg], ga.x, be.x), fmaf((v.y - mean[rg]) * rstd[rg], ga.y, be.y)),
-                   equss::pack_bf16(fmaf((v.z - mean[rg]) * rstd[rg], ga.z, be.z), fmaf((v.w - mean[rg]) * rstd[rg], ga.w, be.w)));
+                fn(rg, nt, equss::pack_bf16(fmaf((v.x - mean) * rstd, ga.x, be.x), fmaf((v.y - mean) * rstd, ga.y, be.y)),
+                   equss::pack_bf16(fmaf((v.z - mean) * rstd, ga.z, be.z), fmaf((v.w - mean) * rstd, ga.w, be.w)));
             }
+            after_group(rg);
+            RS_PIN();
         }
     };
 
     // ---- LayerNorm2 of the updated rows -> xs (bf16, fragment order), over the attention rows ----------------------------
     // (every wave passes the two barriers inside only after its last read of the attention rows)
     {
+        const int l_ = olane(), fr = l_ & 15, col0 = wave * WN + (l_ >> 4) * 4;
         int ln2_off[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = col0 + nt * 16, kk = col & 31;   // slice col / 32, 16-byte piece kk / 8 of row fr, half (kk / 4) & 1
             ln2_off[nt] = (col >> 5) * (NGMAX * 1024) + ((kk >> 3) * 16 + fr) * 16 + ((kk >> 2) & 1) * 8;
         }
-        layer_norm(gamma2_s, beta2_s, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
+        layer_norm(gamma2_s, beta2_s, [] {}, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
             *reinterpret_cast<uint2*>(xs + ln2_off[nt] + rg * 1024) = uint2{lo, hi};
-        });
+        }, [](int) {});
     }
     lds_barrier();
+    RS_STAMP();   // LayerNorm2 done
 
 #pragma unroll 1
     for (int c = 0; c < NCH; ++c) {
@@ -242,17 +349,22 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
 #pragma unroll
             for (int n1 = 0; n1 < NT1; ++n1) acc1[rg][n1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+        for (int rg = 0; rg < NG; ++rg) a[rg] = frag_x(0, rg);
+        RS_PIN();
+#pragma unroll
         for (int s = 0; s < KS; ++s) {
-            L4 a[NG];
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg) a[rg] = *reinterpret_cast<const L4*>(xs + (s * NGMAX + rg) * 1024 + lane * 16);
+            for (int rg = 0; rg < NG; ++rg) {
+                if (active(rg)) {
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg)
-#pragma unroll
-                for (int n1 = 0; n1 < NT1; ++n1) {
-                    const int f = s * NT1 + n1;   // fragment f of the chunk's W1 stream: group f / 3, member f % 3
-                    acc1[rg][n1] = MM(wr[(f / GW) % PD][f % GW], a[rg], acc1[rg][n1]);
+                    for (int n1 = 0; n1 < NT1; ++n1) {
+                        const int f = s * NT1 + n1;   // fragment f of the chunk's W1 stream: group f / 3, member f % 3
+                        acc1[rg][n1] = MM(wr[(f / GW) % PD][f % GW], a[rg], acc1[rg][n1]);
+                    }
+                    if (s + 1 < KS) a[rg] = frag_x(s + 1, rg);
                 }
+                RS_PIN();
+            }
             // a group whose last fragment was used in this step makes room for the group PD further on
 #pragma unroll
             for (int j = 0; j < KS * NT1 / GW; ++j)
@@ -260,24 +372,37 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
 #pragma unroll
                     for (int e = 0; e < GW; ++e) wr[j % PD][e] = wload((j + PD) * GW + e, wc);
                 }
+            RS_PIN();
         }
+        RS_STAMP();   // G1 done
         // ---- gelu(h + b1) -> hs: this wave's 32 hidden units are k slice `wave` of the chunk ------------------------------
         lds_barrier();   // every wave is past its reads of the previous chunk's hidden tile (and of the statistics scratch)
+        RS_STAMP();   // hidden tile free
+        const int l_ = olane(), fr = l_ & 15, fq = l_ >> 4, col0 = wave * WN + fq * 4;
+        // The next tile's attention rows: requested here in the last chunk (every wave is past its last read of xs), they land
+        // under that chunk's GELU and G2.
+        if (c == NCH - 1) dma_att(g, xs, next_row0, next_nrows, l_, wave);
 #pragma unroll
         for (int n1 = 0; n1 < NT1; ++n1) {
             const f32x4 b = *reinterpret_cast<const f32x4*>(b1_s + c * HC + wave * (HC / NW) + n1 * 16 + fq * 4);
             char* const dst = hs + wave * (NGMAX * 1024) + ((n1 * 2 + (fq >> 1)) * 16 + fr) * 16 + (fq & 1) * 8;
+            // (two row groups = four polynomial chains at a time, written step by step: one chain after the other leaves
+            // the vector pipe waiting for its own results)
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg) {
-                f32x4 v = acc1[rg][n1];
-                add4(v, b);
+            for (int rg = 0; rg < NG; rg += 2) {
+                if (!active(rg)) continue;
+                const bool two = rg + 1 < NG && active(rg + 1);
+                f32x4 v0 = acc1[rg][n1], v1 = acc1[rg + 1 < NG ? rg + 1 : rg][n1];
+                add4(v0, b);
+                add4(v1, b);
 #ifndef EQUSS_ABL_RSNOGELU
-                const equss::gelu_f32x2 g0 = equss::gelu_erf2(equss::gelu_f32x2{v.x, v.y});
-                const equss::gelu_f32x2 g1 = equss::gelu_erf2(equss::gelu_f32x2{v.z, v.w});
+                equss::gelu_f32x2 o[4] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w}};
+                equss::gelu_erf2x4(o);
 #else
-                const equss::gelu_f32x2 g0 = {v.x, v.y}, g1 = {v.z, v.w};
+                const equss::gelu_f32x2 o[4] = {{v0.x, v0.y}, {v0.z, v0.w}, {v1.x, v1.y}, {v1.z, v1.w}};
 #endif
-                *reinterpret_cast<uint2*>(dst + rg * 1024) = uint2{equss::pack_bf16(g0.x, g0.y), equss::pack_bf16(g1.x, g1.y)};
+                *reinterpret_cast<uint2*>(dst + rg * 1024) = uint2{equss::pack_bf16(o[0].x, o[0].y), equss::pack_bf16(o[1].x, o[1].y)};
+                if (two) *reinterpret_cast<uint2*>(dst + (rg + 1) * 1024) = uint2{equss::pack_bf16(o[2].x, o[2].y), equss::pack_bf16(o[3].x, o[3].y)};
             }
         }
         if (c == 0) {
@@ -288,42 +413,98 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
                 for (int rg = 0; rg < NG; ++rg) add4(acc2[rg][nt], b);
             }
         }
+        RS_STAMP();   // GELU done
         lds_barrier();   // the hidden tile is complete
+        RS_STAMP();   // hidden tile complete
         // ---- G2: acc2 += h W2[:, chunk]^T (8 k slices; groups 8 .. 15 of the chunk) --------------------------------------
 #pragma unroll
+        for (int rg = 0; rg < NG; ++rg) a[rg] = frag_h(0, rg);
+        RS_PIN();
+#pragma unroll
         for (int ks = 0; ks < KS2; ++ks) {
-            L4 a[NG];
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg) a[rg] = *reinterpret_cast<const L4*>(hs + (ks * NGMAX + rg) * 1024 + lane * 16);
+            for (int rg = 0; rg < NG; ++rg) {
+                if (active(rg)) {
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc2[rg][nt] = MM(wr[ks % PD][nt], a[rg], acc2[rg][nt]);
+                    for (int nt = 0; nt < NT; ++nt) acc2[rg][nt] = MM(wr[ks % PD][nt], a[rg], acc2[rg][nt]);
+                    if (ks + 1 < KS2) a[rg] = frag_h(ks + 1, rg);
+                }
+                RS_PIN();
+            }
 #pragma unroll
             for (int e = 0; e < GW; ++e) wr[ks % PD][e] = wload((KS * NT1 / GW + ks + PD) * GW + e, wc);
+            RS_PIN();
         }
+        RS_STAMP();   // G2 done
     }
+    RS_STAMP();   // last G2 done
     lds_barrier();   // the hidden tile is free: statistics scratch
+    RS_STAMP();
 
     // ---- epilogue: LayerNorm of the final rows as bf16, x back -------------------------------------------------------------
-    if (g.ln) {
-        const __amdgpu_buffer_rsrc_t ln_rs = rows_rsrc(g.ln, g.ld_ln * 2, row0, nrows);
-        const uint32_t ln_lane = (uint32_t)(fr * (int)g.ld_ln + col0) * 2u;
-        const uint32_t ln_rg = 32u * (uint32_t)g.ld_ln;
-        layer_norm(gamma_s, beta_s, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
-            typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(u32x2_t{lo, hi}, ln_rs, ln_lane + nt * 32, rg * ln_rg, 0);
-        });
-    }
+    // A lane holds four columns of one row, so a store instruction straight from the accumulators writes sixteen pieces of
+    // 64 bytes (x) or 32 bytes (LayerNorm rows) in sixteen rows, and such stores leave a CU at a fraction of its store
+    // rate.  Instead each 16-row group goes through a staging tile in the free hidden-tile space: the eight waves write
+    // their columns, a barrier, then every wave instruction stores 1 KiB of consecutive memory.
+    constexpr int kXFirst = 5;   // row groups of the next tile's residual rows requested before the first store
+    constexpr int kStgX = kStatS + NGMAX * 16 * 4 * 8, kRowX = C * 4 + 16, kStgL = kStgX + 16 * kRowX, kRowL = C * 2 + 16;
+    static_assert(kStgL + 16 * kRowL <= kHs, "staging tiles must fit the hidden tile");
+    const int l_ = olane(), fr = l_ & 15, fq = l_ >> 4, col0 = wave * WN + fq * 4;
+    const __amdgpu_buffer_rsrc_t ln_rs = rows_rsrc(g.ln, g.ld_ln * 2, row0, g.ln ? nrows : 0);
+    auto group_out = [&](int rg) {
+        // this wave's columns of the group's rows -> staging (padded rows: conflict free)
 #pragma unroll
-    for (int rg = 0; rg < NG; ++rg)
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(hs + kStgX + fr * kRowX + (col0 + nt * 16) * 4) = acc2[rg][nt];
+        RS_STAMP();   // (group normalised and written to the staging tiles)
+        lds_barrier();
+        RS_STAMP();
+        // 24 KiB of x = 24 pieces of 1 KiB, three per wave; 12 KiB of LayerNorm rows = 12 pieces
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#ifndef EQUSS_ABL_RSNOX
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(L4, acc2[rg][nt]), x_rs, x_lane + nt * 64, rg * x_rg, 2);
+        for (int j = 0; j < 3; ++j) {
+            const int flat = (wave * 3 + j) * 1024 + l_ * 16, r = flat / (C * 4), cb = flat % (C * 4);
+            const L4 d = *reinterpret_cast<const L4*>(hs + kStgX + r * kRowX + cb);
+#if !defined(EQUSS_ABL_RSNOX) && !defined(EQUSS_ABL_RSNOST)
+            __builtin_amdgcn_raw_buffer_store_b128(d, x_rs, (uint32_t)(r * (int)g.ldx * 4 + cb), rg * x_rg, 2);
 #else
-            asm volatile("" ::"v"(acc2[rg][nt]));
+            asm volatile("" ::"v"(d));
 #endif
+        }
+        if (g.ln) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = wave + NW * j;
+                if (q < 12) {
+                    const int flat = q * 1024 + l_ * 16, r = flat / (C * 2), cb = flat % (C * 2);
+                    const L4 d = *reinterpret_cast<const L4*>(hs + kStgL + r * kRowL + cb);
+#ifndef EQUSS_ABL_RSNOST
+                    __builtin_amdgcn_raw_buffer_store_b128(d, ln_rs, (uint32_t)(r * (int)g.ld_ln * 2 + cb), rg * 32u * (uint32_t)g.ld_ln, 0);
+#else
+                    asm volatile("" ::"v"(d));
+#endif
+                }
+            }
+        }
+        RS_STAMP();   // (stores issued)
+        lds_barrier();   // the staging tiles are free again
+        RS_STAMP();
+        // (the last two groups of the next tile's residual rows go into the accumulator registers that two finished groups
+        // have left: all seven at once would not fit beside the accumulators)
+        if (rg == 1) request_x<kXFirst, NGMAX>(g, xr, next_row0, next_nrows, l_, wave);
+    };
+    if (g.ln) {
+        // (the next tile's residual rows are requested between the sums and the stores, into the registers of the G1
+        // accumulators and fragments)
+        layer_norm(gamma_s, beta_s, [&] { request_x<0, kXFirst>(g, xr, next_row0, next_nrows, l_, wave); }, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
+            *reinterpret_cast<uint2*>(hs + kStgL + fr * kRowL + (col0 + nt * 16) * 2) = uint2{lo, hi};
+        }, group_out);
+    } else {
+        request_x<0, kXFirst>(g, xr, next_row0, next_nrows, l_, wave);
+#pragma unroll
+        for (int rg = 0; rg < NG; ++rg)
+            if (active(rg)) group_out(rg);
+    }
+    RS_STAMP();   // epilogue issued
+#undef RS_PIN
     // (the next tile's first writes go to xs, whose last readers passed several barriers ago; its first write to the
     // statistics scratch comes after its own first barrier, which every wave reaches only after the reads above)
 }
@@ -341,7 +522,19 @@ __global__ __launch_bounds__(kThreads, 1) void block_rs_kernel(const RsArgs g) {
     const int g_begin = bid * gq + (bid < gr ? bid : gr), g_len = gq + (bid < gr ? 1 : 0);
     if (g_len == 0) return;
     const int n_tiles = (g_len + NGMAX - 1) / NGMAX;
-    const int tq = g_len / n_tiles, tr = g_len % n_tiles;   // tr tiles of tq + 1 groups, then tiles of tq
+    // Tile heights.  Every tile boundary is a burst of row traffic (the finished tile's rows out, the next tile's in) during
+    // which the workgroup computes nothing; with equal heights everywhere all 256 workgroups burst at the same moments and
+    // share the HBM rate.  So a workgroup's first tile is 0 .. 3 groups shorter than the balanced height, by class
+    // (bid / 8) % 4 (workgroups b and b + 8 share an XCD: every XCD has all classes), and the rest of its run is cut
+    // evenly: boundaries of different classes fall about a group's time apart.
+    int h0 = (g_len + n_tiles - 1) / n_tiles;
+    if (n_tiles > 1 && g.stagger >= 10) {
+        int cut = ((bid >> 3) % (g.stagger / 10)) * (g.stagger % 10);   // (stagger = 10 classes + groups per class step)
+        while (cut > 0 && (h0 - cut < 1 || g_len - (h0 - cut) > NGMAX * (n_tiles - 1))) --cut;
+        h0 -= cut;
+    }
+    const int rest = g_len - h0, nrest = n_tiles > 1 ? n_tiles - 1 : 1;
+    const int tq = rest / nrest, tr = rest % nrest;   // after the first tile: tr tiles of tq + 1 groups, then tiles of tq
 
     float* const par = reinterpret_cast<float*>(smem + kOffPar);
     for (int i = tid; i < HID; i += kThreads) par[i] = g.b1[i];
@@ -362,18 +555,36 @@ __global__ __launch_bounds__(kThreads, 1) void block_rs_kernel(const RsArgs g) {
 #pragma unroll
         for (int e = 0; e < GW; ++e) wr[p][e] = __builtin_amdgcn_raw_buffer_load_b128(w_rs, lane * 16, (p * GW + e) * 1024, 0);
 
+    int stamp_n = 0;
     int gpos = g_begin;
+    // the first tile's rows (every later tile's are requested by the tile before it)
+    f32x4 xr[NGMAX][NT];
+    {
+        const int ng0 = h0, nrows0 = g.M - gpos * 16 < ng0 * 16 ? g.M - gpos * 16 : ng0 * 16;
+        L4 pre0[kAttHalf], pre1[kAttHalf];
+        request_x(g, xr, gpos * 16, nrows0, lane, wave);
+        request_att<0>(g, pre0, gpos * 16, nrows0, lane, wave);
+        request_att<1>(g, pre1, gpos * 16, nrows0, lane, wave);
+        stage_att<0>(smem, pre0, lane, wave);
+        stage_att<1>(smem, pre1, lane, wave);
+    }
 #pragma unroll 1
     for (int t = 0; t < n_tiles; ++t) {
-        const int ng = tq + (t < tr ? 1 : 0);
+        const int ng = t == 0 ? h0 : tq + (t - 1 < tr ? 1 : 0);
         const int row0 = gpos * 16;
         const int nrows = g.M - row0 < ng * 16 ? g.M - row0 : ng * 16;
-        if (ng == 7) rs_tile<7>(g, smem, wr, w_rs, row0, nrows, lane, wave);
-        else if (ng == 6) rs_tile<6>(g, smem, wr, w_rs, row0, nrows, lane, wave);
-        else if (ng == 5) rs_tile<5>(g, smem, wr, w_rs, row0, nrows, lane, wave);
-        else rs_tile<4>(g, smem, wr, w_rs, row0, nrows, lane, wave);
+        const int ng_next = t + 1 < n_tiles ? tq + (t < tr ? 1 : 0) : 0;
+        const int next_row0 = (gpos + ng) * 16;
+        int next_nrows = g.M - next_row0 < ng_next * 16 ? g.M - next_row0 : ng_next * 16;
+        next_nrows = next_nrows < 0 ? 0 : next_nrows;
+        rs_tile(g, smem, wr, w_rs, xr, ng, row0, nrows, next_row0, next_nrows, lane, wave, &stamp_n);
         gpos += ng;
     }
+#ifdef EQUSS_ABL_RSSTAMPS
+    __syncthreads();
+    if (g.ln && blockIdx.x == kStampWg)   // (launches that write LayerNorm rows: every block's but the last)
+        for (int i = tid; i < NW * kStampMax; i += kThreads) g_rs_stamps[i] = reinterpret_cast<const uint32_t*>(smem + kLds)[i];
+#endif
 }
 
 // One thread per 16 bytes of a block's weight streams:
@@ -408,7 +619,11 @@ __global__ __launch_bounds__(256) void pack_rs_weights_kernel(const RsPackArgs a
     *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(src);
 }
 
+int g_rs_stagger = 41;   // developer switch: 10 * classes + step (in 16-row groups) between the first tiles of two classes
+
 }  // namespace
+
+extern "C" void equss_dev_rs_stagger(int on) { g_rs_stagger = on >= 10 ? on : 0; }   // tuning knob, not part of the ABI
 
 namespace equss {
 
@@ -445,13 +660,25 @@ int block_rs(const void* att, int64_t lda0, const void* image, const float* bp, 
     g.Wimg = reinterpret_cast<const u16*>(image);
     g.bp = bp; g.gamma2 = gamma2; g.beta2 = beta2; g.b1 = b1; g.b2 = b2;
     g.x = x; g.ldx = ldx; g.gamma = gamma; g.beta = beta; g.ln = reinterpret_cast<u16*>(ln); g.ld_ln = ld_ln;
-    g.eps = eps; g.M = M;
+    g.eps = eps; g.M = M; g.stagger = g_rs_stagger;
     const int groups = (M + 15) / 16;
     const int grid = groups < 256 ? groups : 256;
-    if (!lds_opt_in(reinterpret_cast<const void*>(block_rs_kernel), kLds))
+    if (!lds_opt_in(reinterpret_cast<const void*>(block_rs_kernel), 163840))
         return fail(EQUSS_E_UNSUPPORTED, "block_rs: cannot reserve %d bytes of LDS", kLds);
-    hipLaunchKernelGGL(block_rs_kernel, dim3(grid), dim3(kThreads), kLds, s, g);
+#ifdef EQUSS_ABL_RSSTAMPS
+    constexpr int kLdsLaunch = kLds + NW * kStampMax * 4;
+    static_assert(kLdsLaunch <= 163840, "stamps must fit the spare LDS");
+#else
+    constexpr int kLdsLaunch = kLds;
+#endif
+    hipLaunchKernelGGL(block_rs_kernel, dim3(grid), dim3(kThreads), kLdsLaunch, s, g);
     return check_launch("block_rs_kernel");
 }
 
 }  // namespace equss
+
+#ifdef EQUSS_ABL_RSSTAMPS
+extern "C" int equss_dev_rs_stamps(uint32_t* host_out) {   // (developer build only) NW x kStampMax stamps of the last launch
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_rs_stamps), sizeof(uint32_t) * NW * kStampMax);
+}
+#endif

@@ -84,6 +84,41 @@ __device__ __forceinline__ gelu_f32x2 gelu_erf2(gelu_f32x2 x) {
     return __builtin_elementwise_fma(-a, e, relu);
 }
 
+// The same for four pairs at a time with the steps of the four evaluations interleaved (same operations per element, so
+// the same bits): a lone evaluation is a chain of dependent packed fmas, each waiting for the one before.
+__device__ __forceinline__ void gelu_erf2x4(gelu_f32x2 (&x)[4]) {
+    gelu_f32x2 relu[4], a[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) relu[i] = gelu_f32x2{fmaxf(x[i].x, 0.f), fmaxf(x[i].y, 0.f)};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a[i] = __builtin_elementwise_fma(gelu_f32x2{2.f, 2.f}, relu[i], -x[i]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        q[i] = __builtin_elementwise_fma(gelu_f32x2{-0.00047328611253760755f, -0.00047328611253760755f}, a[i],
+                                         gelu_f32x2{0.007084404584020376f, 0.007084404584020376f});
+    __builtin_amdgcn_sched_barrier(0);   // (the steps stay apart: the scheduler would put each chain back together)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], gelu_f32x2{-0.051827020943164825f, -0.051827020943164825f});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], gelu_f32x2{-0.45999282598495483f, -0.45999282598495483f});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], gelu_f32x2{-1.1507877111434937f, -1.1507877111434937f});
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) q[i] = __builtin_elementwise_fma(q[i], a[i], gelu_f32x2{-1.000037670135498f, -1.000037670135498f});
+    __builtin_amdgcn_sched_barrier(0);
+    gelu_f32x2 e[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = gelu_f32x2{__builtin_amdgcn_exp2f(q[i].x), __builtin_amdgcn_exp2f(q[i].y)};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        x[i] = __builtin_elementwise_fma(-a[i], e[i], relu[i]);
+    }
+}
+
 // LDS stores the compiler's wait-count pass does not see.  After a global_load_lds_* the compiler puts
 // s_waitcnt vmcnt(0) in front of every LDS store it emits, because the DMA's destination might alias it; in the
 // ring kernels that drains every stage in flight and every global store the wave has issued, at each epilogue.

@@ -18,6 +18,7 @@ EPI_BF16, EPI_GELU_BF16, EPI_RELU_BF16, EPI_F32, EPI_RESID_F32 = 0, 1, 2, 3, 4
 DEV_SYMBOLS = [   # include/equss_hip_dev.h: developer knobs, not part of the drop-in ABI
     "equss_dev_pq_mode", "equss_dev_gemm_variant", "equss_dev_gemm_stages", "equss_dev_ws_bk", "equss_dev_gemm_cu_share",
     "equss_dev_attn_diag", "equss_dev_mlp_fused", "equss_dev_mlp_tail_max", "equss_dev_fuse_min_tiles", "equss_dev_tail_images", "equss_dev_block_ws",
+    "equss_dev_rs_stagger",
 ]
 
 EXPORTED_SYMBOLS = [

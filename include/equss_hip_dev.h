@@ -37,8 +37,11 @@ void equss_dev_fuse_min_tiles(int tiles);
 void equss_dev_tail_images(int on);
 /* 1 (default): inside equss_vit_forward the producer / consumer block-tail kernel (64-row tiles, csrc/block_ws.hip);
  * 2: the same with four consumer waves of 64 rows instead of eight of 32;
- * 0: the eight-wave kernel of equss_block_tail_bf16 on the whole rounds of 128-row tiles + small-tile launches for the rest. */
+ * 0: the eight-wave kernel of equss_block_tail_bf16 on the whole rounds of 128-row tiles + small-tile launches for the rest;
+ * 3: the register-streamed kernel (csrc/block_rs.hip: weights global -> registers in fragment order, activations in LDS). */
 void equss_dev_block_ws(int on);
+/* block_rs kernel: 1 (default) first tiles of different heights per workgroup class, so that tile boundaries do not coincide. */
+void equss_dev_rs_stagger(int on);
 
 #ifdef __cplusplus
 }

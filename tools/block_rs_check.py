@@ -14,6 +14,8 @@ torch.manual_seed(0)
 net = pkg.featurizer.vit_small(patch_size=8).to(dev).eval()
 lib = nat.load_library()
 lib.equss_dev_fuse_min_tiles(ctypes.c_int(1))
+if os.environ.get("RS_STAGGER"):
+    lib.equss_dev_rs_stagger(ctypes.c_int(int(os.environ["RS_STAGGER"])))
 ok = True
 for batch in batches:
     img = torch.randn(batch, 3, 320, 320, device=dev)
