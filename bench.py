@@ -75,6 +75,105 @@ def algorithmic_work(cfg, batch, height, width, block_ws=True):
     return w
 
 
+def _timed(fn, warmup, steps):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_workloads(pkg, dev, res):
+    """The other configurations of the metric's family, each on a handful of steps after the timed region (bounded:
+    about ten seconds in all): ViT-B/8 + 16 x 512 PQ at 768 x 768, the eval loop with probes and metrics, one training step."""
+    out = {}
+    # ---- ViT-B/8, D = 2048, 16 x 512 PQ, 2 x 768 x 768 per GPU ------------------------------------------------------
+    cfg_b = pkg.configs.B_CFG
+    model_b = pkg.build_model(cfg_b)
+    model_b.load_state_dict(pkg.synth.synth_pqgo_state(cfg_b, seed=1234), strict=True)
+    model_b = model_b.to(dev).eval()
+    img_b = pkg.synth.synth_images(2, 768, 768, seed=7).to(dev)
+
+    def step_b():
+        with torch.no_grad():
+            model_b.model(img=img_b)
+    s_b = _timed(step_b, 2, 4)
+    pkg.native.profile_enable(4096)
+    step_b()
+    prof = pkg.native.profile_read(reset=True)
+    pkg.native.profile_enable(0)
+    work_b = algorithmic_work(cfg_b, 2, 768, 768)
+    pq_ms, pq_n = prof["pq_assign"]
+    flops_b = sum(work_b[k]["flops"] * prof[k][1] for k in work_b if "flops" in work_b[k] and k in prof and prof[k][1])
+    out["vit_b8_768"] = {"workload": "ViT-B/8 + head (D=2048) + 16 x 512 PQ, 2 x 768x768, eval forward",
+                         "images_per_s": round(2 / s_b, 2), "ms_per_step": round(s_b * 1e3, 3),
+                         "model_tflops": round(flops_b / s_b / 1e12, 1),
+                         "pq_assign_us": round(pq_ms / max(pq_n, 1) * 1e3, 1),
+                         "pq_assign_frac_of_hbm_peak": round(work_b["pq_assign"]["bytes"] / (pq_ms / max(pq_n, 1) / 1e3) / PEAK_HBM, 4)}
+    del model_b, img_b
+    torch.cuda.empty_cache()
+    # ---- eval loop: wrapper forward (ViT + head + PQ + probes) + confusion-matrix updates + compute() ------------------
+    cfg = pkg.configs.S_CFG
+    ncls = cfg["num_classes"]
+    state = pkg.synth.synth_pqgo_state(cfg, seed=1234)
+    wrapper = pkg.build_model(cfg)
+    wrapper.load_state_dict(state, strict=True)
+    wrapper = wrapper.to(dev).eval()
+    cluster_m = pkg.UnSegMetrics(ncls, cfg["eval"]["extra_classes"], True, dev)
+    linear_m = pkg.UnSegMetrics(ncls, 0, False, dev)
+    pool = [(pkg.synth.synth_images(64, res, res, seed=100 + i).to(dev),
+             pkg.synth.synth_labels(64, res, res, ncls, seed=100 + i).to(dev)) for i in range(2)]
+
+    def eval_loop(n):
+        cluster_m.reset()
+        linear_m.reset()
+        with torch.no_grad():
+            for i in range(n):
+                img, label = pool[i % len(pool)]
+                _t, _o, (lin_p, clu_p), _f = wrapper(img, img, label)
+                cluster_m.update(clu_p, label)
+                linear_m.update(lin_p, label)
+        return cluster_m.compute("cluster"), linear_m.compute("linear")
+    eval_loop(1)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res_c, res_l = eval_loop(6)
+    torch.cuda.synchronize()
+    s_e = time.perf_counter() - t0
+    out["eval_loop"] = {"workload": f"eval loop, 6 batches of 64 x {res}x{res}: wrapper forward (ViT-S/8 + head + PQ + probes) + "
+                                    "metric updates + compute()",
+                        "images_per_s": round(6 * 64 / s_e, 1), "cluster_miou": round(float(res_c["iou"]), 4),
+                        "linear_miou": round(float(res_l["iou"]), 4)}
+    del wrapper, pool
+    torch.cuda.empty_cache()
+    # ---- one training step: 16 x 224 x 224 (config/pqgo_baseline.yaml:135,146), train.py:74-98 ------------------------
+    cfg_t = pkg.configs.pqgo_config(need_initialized="uni")
+    trainee = pkg.build_model(cfg_t)
+    trainee.load_state_dict(pkg.synth.synth_pqgo_state(cfg_t, seed=1234), strict=True)
+    trainee = trainee.to(dev).train()
+    optim = torch.optim.Adam([p for p in trainee.parameters() if p.requires_grad], lr=3e-4)
+    img_t = pkg.synth.synth_images(16, 224, 224, seed=1).to(dev)
+    pos_t = pkg.synth.synth_images(16, 224, 224, seed=101).to(dev)
+    lab_t = pkg.synth.synth_labels(16, 224, 224, cfg_t["num_classes"], seed=1).to(dev)
+    it = [0]
+
+    def train_step():
+        optim.zero_grad(set_to_none=True)
+        total, _o, _p, _f = trainee(img=img_t, aug_img=img_t, label=lab_t, img_pos=pos_t, it=it[0])
+        total.backward()
+        torch.nn.utils.clip_grad_norm_(trainee.model.parameters(), max_norm=10.0)
+        optim.step()
+        it[0] += 1
+    s_t = _timed(train_step, 3, 8)
+    out["train_step"] = {"workload": "training step, 16 x 224x224: two frozen ViT-S/8 passes + head / codebooks / probes forward, "
+                                     "backward, clip, Adam", "ms_per_step": round(s_t * 1e3, 3),
+                         "images_per_s": round(16 / s_t, 1)}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +186,8 @@ def main():
                     help="HIP streams the batch's image ranges are spread over inside one step (1 = one stream)")
     ap.add_argument("--dev", action="append", default=[], metavar="KNOB=INT",
                     help="developer tuning knob of the library (equss_dev_KNOB), for experiments only")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the fp32-mode and secondary-workload legs (B-cfg 768, eval loop, training step) after the timed region")
     ap.add_argument("--cfg", choices=["s", "b"], default="s",
                     help="s = ViT-S/8, D=1024, 8x256 PQ (the headline workload); b = ViT-B/8, D=2048, 16x512 PQ "
                          "(use with --res 768 --batch 2..4)")
@@ -166,7 +267,7 @@ def main():
 
     knobs = dict(kv.split("=") for kv in args.dev)
     work = algorithmic_work(cfg, args.batch, args.res, args.res,
-                            block_ws=int(knobs.get("block_ws", 1)) != 0 and int(knobs.get("tail_images", 1)) != 0)
+                            block_ws=int(knobs.get("block_ws", 3)) != 0 and int(knobs.get("tail_images", 1)) != 0)
     # HBM bytes per launch from the PMC counters are measured by separate rocprofv3 passes (profiles/): they
     # are quoted only while the kernel sources still hash to what those passes ran, otherwise null
     traffic = {}
@@ -251,6 +352,23 @@ def main():
                         "sample": f"model forward (ViT+head+PQ) on 4 images {args.res}x{args.res}, fp32, "
                                   f"best of {runs} runs after 1 warm-up, {spent:.1f} s of CPU time"}
 
+    # ---- the mode whose code indices equal the reference's (index_match.e2e_fp32_mode_vs_fp32_reference), at the same batch ----
+    fp32_mode = None
+    secondary = None
+    if world == 1 and not args.no_secondary:
+        model.model.precision = "fp32"
+        model.model.eval_streams = 1
+        s_f = _timed(step, 1, 3)
+        model.model.precision = "bf16"
+        fp32_mode = {"images_per_s": round(args.batch / s_f, 2), "ms_per_step": round(s_f * 1e3, 3),
+                     "what": "the same forward with DIONPQGO.precision = 'fp32' (every GEMM and the attention in fp32 on the "
+                             "matrix cores): the mode whose code indices equal the fp32 reference's",
+                     "vs_cpu_baseline": round(args.batch / s_f / cpu_baseline["value"], 1) if cpu_baseline else None}
+        if args.cfg == "s":
+            del model
+            torch.cuda.empty_cache()
+            secondary = secondary_workloads(pkg, dev, args.res)
+
     line = {
         "metric": "images/sec (320x320) end-to-end fwd+PQ-assign; PQ code-index exact-match vs ref",
         "value": round(world * args.batch * args.steps / elapsed, 2),
@@ -277,6 +395,8 @@ def main():
         "kernels": kernels,
         "cpu_baseline": cpu_baseline,
         "index_match": index_match,
+        "fp32_mode": fp32_mode,
+        "secondary": secondary,
     }
     print(json.dumps(line))
     if dist is not None:

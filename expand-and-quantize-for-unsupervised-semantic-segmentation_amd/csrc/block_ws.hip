@@ -460,7 +460,7 @@ __global__ __launch_bounds__((4 * WM + NP) * 64, 1) void block_ws_kernel(const B
     }
 }
 
-int g_block_ws = 1;   // developer switch: 1 (default) = this kernel inside equss_vit_forward, 0 = mlp_kernel<true, true>
+int g_block_ws = 3;   // developer switch: 3 (default) = block_rs_kernel inside equss_vit_forward, 1 = this kernel, 0 = mlp_kernel<true, true>
 
 }  // namespace
 

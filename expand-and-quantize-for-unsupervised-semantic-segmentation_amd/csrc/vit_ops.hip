@@ -489,14 +489,19 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
     // The fused block-tail kernel reads the projection / fc1 weights as ring-stage images: written here, once per forward
     // for all blocks (one launch, ~17 MB), when that kernel is going to run.
     bool images = false;
+    const char* wimg = w.wimg;
     if (g_tail_images && w.wimg && g_mlp_fused == 2 && (rows + 127) / 128 >= g_fuse_min_tiles && equss::gemm8_resid_ln_supports(C, C) &&
         equss::mlp_fused_supports(C, 4 * C)) {
-        const void* wp[16]; const void* w1[16]; const void* w2[16];
-        for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; w2[i] = vit->blocks[i].fc2_w; }
-        equss::ProfScope ps(EQUSS_K_GEMM_PROJ, s);
-        rc = equss::block_ws_mode() == 3 ? equss::pack_rs_weights(wp, w1, w2, vit->depth, w.wimg, tail_image_stride(), s)
-                                         : equss::pack_tail_weights(wp, w1, w2, vit->depth, w.wimg, tail_image_stride(), s);
-        if (rc) return rc;
+        if (vit->tail_images && equss::block_ws_mode() == 3) {
+            wimg = reinterpret_cast<const char*>(vit->tail_images);   // written once for these weights (equss_vit_pack_tail_images)
+        } else {
+            const void* wp[16]; const void* w1[16]; const void* w2[16];
+            for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; w2[i] = vit->blocks[i].fc2_w; }
+            equss::ProfScope ps(EQUSS_K_PACK_WEIGHTS, s);
+            rc = equss::block_ws_mode() == 3 ? equss::pack_rs_weights(wp, w1, w2, vit->depth, w.wimg, tail_image_stride(), s)
+                                             : equss::pack_tail_weights(wp, w1, w2, vit->depth, w.wimg, tail_image_stride(), s);
+            if (rc) return rc;
+        }
         images = true;
     }
     const float scale = 0.125f;  // head_dim ** -0.5 with head_dim = 64 (vision_transformer.py:71-72)
@@ -523,7 +528,7 @@ int vit_forward_impl(const EqussVit* vit, const float* img, const float* pos, vo
         if (fuse && big && g_mlp_fused == 2 && equss::mlp_fused_supports(C, 4 * C)) {
             const EqussVitBlock* nb = last ? nullptr : &vit->blocks[i + 1];
             return block_balanced(w.att, k.proj_w, k.proj_b, k.ln2_g, k.ln2_b, w.ln, k.fc1_w, k.fc1_b, k.fc2_w, k.fc2_b, w.x, nb ? nb->ln1_g : nullptr, nb ? nb->ln1_b : nullptr, nb ? w.ln : nullptr, w.hid, rows, 1e-6f, s,
-                                  images ? w.wimg + (size_t)i * tail_image_stride() : nullptr);
+                                  images ? wimg + (size_t)i * tail_image_stride() : nullptr);
         }
         if (fuse) {
             EQUSS_STEP(EQUSS_K_GEMM_PROJ, resid_ln_balanced(w.att, C, k.proj_w, C, k.proj_b, w.x, C, k.ln2_g, k.ln2_b, w.ln, C, rows, C, C, 1e-6f, s))
@@ -578,6 +583,22 @@ int check_vit(const EqussVit* vit, const float* img, const float* pos, void* wor
     return EQUSS_OK;
 }
 }  // namespace
+
+extern "C" size_t equss_vit_tail_image_bytes(const EqussVit* vit) {
+    if (!vit || vit->depth < 1 || vit->depth > 16 || !equss::mlp_fused_supports(vit->embed_dim, 4 * vit->embed_dim)) return 0;
+    return tail_image_stride() * (size_t)vit->depth;
+}
+
+extern "C" int equss_vit_pack_tail_images(const EqussVit* vit, void* images, size_t images_bytes, void* stream) {
+    if (!vit || !vit->blocks || !images) return equss::fail(EQUSS_E_NULL, "vit_pack_tail_images: null pointer argument");
+    const size_t need = equss_vit_tail_image_bytes(vit);
+    if (need == 0) return equss::fail(EQUSS_E_UNSUPPORTED, "vit_pack_tail_images: embed dim %d has no fused block-tail kernel", vit->embed_dim);
+    if (images_bytes < need) return equss::fail(EQUSS_E_WORKSPACE, "vit_pack_tail_images: %zu bytes given, %zu needed", images_bytes, need);
+    if ((uintptr_t)images % 256) return equss::fail(EQUSS_E_ALIGN, "vit_pack_tail_images: images must be 256-byte aligned");
+    const void* wp[16]; const void* w1[16]; const void* w2[16];
+    for (int i = 0; i < vit->depth; ++i) { wp[i] = vit->blocks[i].proj_w; w1[i] = vit->blocks[i].fc1_w; w2[i] = vit->blocks[i].fc2_w; }
+    return equss::pack_rs_weights(wp, w1, w2, vit->depth, images, tail_image_stride(), reinterpret_cast<hipStream_t>(stream));
+}
 
 extern "C" int equss_vit_forward(const EqussVit* vit, const float* img, const float* pos, void* feat_bf16,
                                  int64_t ld_feat, float* feat_f32, void* workspace, size_t workspace_bytes, int B,

@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = [
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_block_tail_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
+    "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
     "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
     "equss_index_rows_i16", "equss_code_usage",
@@ -49,7 +50,7 @@ class VitStruct(ctypes.Structure):
                 ("patch", ctypes.c_int32),
                 ("patch_w", ctypes.c_void_p), ("patch_b", ctypes.c_void_p), ("cls", ctypes.c_void_p),
                 ("norm_g", ctypes.c_void_p), ("norm_b", ctypes.c_void_p),
-                ("blocks", ctypes.POINTER(VitBlockStruct))]
+                ("blocks", ctypes.POINTER(VitBlockStruct)), ("tail_images", ctypes.c_void_p)]
 
 
 _lib = None
@@ -100,6 +101,10 @@ def _declare(lib):
                                        c_int, c_int, c_int, c_int, c_int, c_vp]
     lib.equss_vit_workspace_bytes.restype = c_sz
     lib.equss_vit_workspace_bytes.argtypes = [ctypes.POINTER(VitStruct), c_int, c_int, c_int]
+    lib.equss_vit_tail_image_bytes.restype = c_sz
+    lib.equss_vit_tail_image_bytes.argtypes = [ctypes.POINTER(VitStruct)]
+    lib.equss_vit_pack_tail_images.restype = c_int
+    lib.equss_vit_pack_tail_images.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_sz, c_vp]
     lib.equss_vit_forward.restype = c_int
     lib.equss_vit_forward.argtypes = [ctypes.POINTER(VitStruct), c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_sz,
                                       c_int, c_int, c_int, c_vp]
@@ -144,7 +149,7 @@ def load_library():
                 if not hasattr(lib, sym):
                     raise EqussError(f"{LIB_PATH} does not export {sym}")
             _declare(lib)
-            if lib.equss_abi_version() != 1:
+            if lib.equss_abi_version() != 2:
                 raise EqussError("libequss_hip.so ABI version mismatch")
             _lib = lib
     return _lib
@@ -193,7 +198,8 @@ def _workspace(device, nbytes, tag):
 
 
 KERNEL_CLASSES = ["patch", "layernorm", "gemm_qkv", "attention", "gemm_proj", "gemm_fc1", "gemm_fc2",
-                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign", "probe_table", "probe_pixels", "mlp_fused", "block_tail"]
+                  "head_gemm1", "head_gemm2", "pq_prep", "pq_assign", "probe_table", "probe_pixels", "mlp_fused", "block_tail",
+                  "pack_weights"]
 
 
 def profile_enable(max_pairs):
@@ -386,7 +392,7 @@ def patch_tokens(img, w_patch, b_patch, cls, pos, patch):
 class VitHandle:
     """Device-resident bf16/fp32 weight set of one backbone plus the host-side EqussVit struct."""
 
-    def __init__(self, tensors, embed_dim, depth, heads, patch):
+    def __init__(self, tensors, embed_dim, depth, heads, patch, pack_tail=True):
         self.tensors = tensors  # keeps the device buffers alive
         self.blocks = (VitBlockStruct * depth)()
         for i in range(depth):
@@ -395,8 +401,19 @@ class VitHandle:
         self.struct = VitStruct(embed_dim, depth, heads, patch,
                                 tensors["patch_w"].data_ptr(), tensors["patch_b"].data_ptr(),
                                 tensors["cls"].data_ptr(), tensors["norm_g"].data_ptr(),
-                                tensors["norm_b"].data_ptr(), self.blocks)
+                                tensors["norm_b"].data_ptr(), self.blocks, None)
         self.embed_dim, self.depth, self.heads, self.patch = embed_dim, depth, heads, patch
+        # The block-tail kernel's weight order, written once per weight set (a handle is rebuilt when a parameter changes)
+        # instead of at the start of every forward.  bf16 sets only: the fp32 parity forward has no such kernel.
+        self.tail_images = None
+        if pack_tail and tensors["patch_w"].is_cuda and tensors["blocks.0.proj_w"].dtype == torch.bfloat16:
+            lib = load_library()
+            nbytes = lib.equss_vit_tail_image_bytes(ctypes.byref(self.struct))
+            if nbytes:
+                self.tail_images = torch.empty(nbytes, dtype=torch.uint8, device=tensors["patch_w"].device)
+                _check(lib.equss_vit_pack_tail_images(ctypes.byref(self.struct), _ptr(self.tail_images), nbytes,
+                                                      _stream(self.tail_images)), "equss_vit_pack_tail_images")
+                self.struct.tail_images = self.tail_images.data_ptr()
 
 
 def vit_forward(handle, img, pos, feat_bf16=None, ld_feat=None, want_f32=False):

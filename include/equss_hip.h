@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define EQUSS_ABI_VERSION 1
+#define EQUSS_ABI_VERSION 2
 
 enum {
     EQUSS_OK = 0,
@@ -82,7 +82,8 @@ enum {
     EQUSS_K_PROBE_PIXELS = 12, /* per-pixel interpolation, arg-max, losses */
     EQUSS_K_MLP_FUSED = 13,    /* fc1 + GELU + fc2 + residual + LayerNorm in one kernel */
     EQUSS_K_BLOCK_TAIL = 14,   /* proj + residual + LayerNorm2 + MLP + residual + LayerNorm in one kernel */
-    EQUSS_K_COUNT = 15
+    EQUSS_K_PACK_WEIGHTS = 15, /* re-ordering of the block-tail weights when the caller has not prepared them */
+    EQUSS_K_COUNT = 16
 };
 int equss_profile_enable(int max_pairs);
 int equss_profile_read(double* ms, int64_t* launches, int reset);
@@ -225,7 +226,17 @@ typedef struct EqussVit {
     const float* cls;                          /* (C) fp32 */
     const float* norm_g; const float* norm_b;  /* final LayerNorm */
     const EqussVitBlock* blocks;               /* HOST array of `depth` entries */
+    const void* tail_images;                   /* DEVICE, optional: equss_vit_pack_tail_images() of these weights, or NULL */
 } EqussVit;
+
+/* The fused kernel behind everything of a block after its attention (vision_transformer.py:110-111 with :58-64) streams
+ * proj / fc1 / fc2 weights in the order its waves consume them.  A caller whose weights are frozen (the reference freezes
+ * the backbone: dino_featurizer.py:20-21) writes that order once and hands it over in EqussVit.tail_images; with NULL
+ * there, every forward re-orders the weights into its workspace first (one extra launch, ~32 MB of traffic).
+ *   images: equss_vit_tail_image_bytes(vit) bytes, 256-byte aligned (0 = this embed dim has no such kernel); must be
+ *   re-packed when proj_w / fc1_w / fc2_w of any block change. */
+size_t equss_vit_tail_image_bytes(const EqussVit* vit);
+int equss_vit_pack_tail_images(const EqussVit* vit, void* images, size_t images_bytes, void* stream);
 
 /* DinoFeaturizer.forward (model/dino/dino_featurizer.py:64-83) = prepare_tokens + all blocks +
  * final norm + drop CLS (vision_transformer.py:227-239 with n=1).

@@ -131,25 +131,28 @@ def test_bcfg_at_its_real_shape_768px(pkg, native, oracle, dev):
 
 
 def test_block_tail_kernels_give_equal_bits_inside_the_vit(pkg, native, dev):
-    """The producer / consumer block-tail kernel (64-row tiles, the default inside the ViT forward) against the eight-wave
-    kernel + small-tile launches it replaces: equal bits of the features, at a row count that leaves a ragged last tile
-    (37 x 1601 rows) and at one that does not divide into rounds either way."""
+    """The register-streamed block-tail kernel (the default inside the ViT forward) against the producer / consumer kernel
+    (64-row tiles) and the eight-wave kernel + small-tile launches: equal bits of the features, at a row count that leaves a
+    ragged last tile (37 x 1601 rows), at one that does not divide into rounds either way, and at a small one where a
+    workgroup's tile has fewer than four 16-row groups."""
     import ctypes
     lib = native.load_library()
     torch.manual_seed(3)
     net = pkg.featurizer.vit_small(patch_size=8).to(dev).eval()
-    for batch in (37, 48):
+    for batch in (37, 48, 5):
         img = torch.randn(batch, 3, 320, 320, device=dev)
         feats = []
         try:
-            for on in (1, 0, 2):   # default (eight consumer waves), the eight-wave kernel, four consumer waves
+            lib.equss_dev_fuse_min_tiles(ctypes.c_int(1))   # (the fused kernels at every row count)
+            for on in (3, 1, 0, 2):   # default, the producer / consumer kernel (eight consumer waves), the eight-wave kernel, four consumer waves
                 lib.equss_dev_block_ws(ctypes.c_int(on))
                 with torch.no_grad():
                     feats.append(net.get_intermediate_feat(img, n=1)[0][0].clone())
         finally:
-            lib.equss_dev_block_ws(ctypes.c_int(1))
+            lib.equss_dev_block_ws(ctypes.c_int(3))
+            lib.equss_dev_fuse_min_tiles(ctypes.c_int(384))
         assert torch.isfinite(feats[0]).all()
-        assert torch.equal(feats[0], feats[1]) and torch.equal(feats[0], feats[2])
+        assert all(torch.equal(feats[0], f) for f in feats[1:])
 
 
 def test_stationary_weights_gemm_gives_equal_bits_inside_the_vit(pkg, native, dev):

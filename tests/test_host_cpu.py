@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol(native):
     for sym in sorted(declared):
         assert hasattr(lib, sym), f"libequss_hip.so does not export {sym}"
     assert declared == set(native.EXPORTED_SYMBOLS)
-    assert lib.equss_abi_version() == 1
+    assert lib.equss_abi_version() == 2
 
 
 def test_library_exports_nothing_undeclared(native):

@@ -38,6 +38,6 @@ for batch in batches:
     d = (outs[1] - outs[3]).abs().max().item()
     print(f"batch {batch:3d} rows {batch * 1601:6d}: block tail {times[1]:7.1f} us (ws) {times[3]:7.1f} us (rs)  equal bits {eq}  max|diff| {d:.3g} "
           f"finite {bool(torch.isfinite(outs[3]).all())}", flush=True)
-lib.equss_dev_block_ws(ctypes.c_int(1))
+lib.equss_dev_block_ws(ctypes.c_int(3))
 lib.equss_dev_fuse_min_tiles(ctypes.c_int(384))
 sys.exit(0 if ok else 1)

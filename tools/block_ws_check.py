@@ -26,6 +26,6 @@ for on in (0, 1, 2, 0, 1, 2):
         e1.record(); torch.cuda.synchronize()
     print(f"block_ws={on}: {e0.elapsed_time(e1) / 5:.3f} ms per forward, finite {bool(torch.isfinite(f).all())}", flush=True)
     outs.setdefault(on, f.clone())
-lib.equss_dev_block_ws(ctypes.c_int(0))
+lib.equss_dev_block_ws(ctypes.c_int(3))
 d = max((outs[0] - outs[1]).abs().max().item(), (outs[0] - outs[2]).abs().max().item())
 print("equal bits:", torch.equal(outs[0], outs[1]), torch.equal(outs[0], outs[2]), " max |diff|:", d)

@@ -10,7 +10,7 @@ source_digest = importlib.import_module("expand-and-quantize-for-unsupervised-se
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-CLASS = [("block_ws_kernel", "block_tail"), ("pack_tail_weights", "pack_weights"), ("mlp_kernel<true", "block_tail"), ("mlp_kernel", "mlp_fused"), ("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
+CLASS = [("block_rs_kernel", "block_tail"), ("pack_rs_weights", "pack_weights"), ("block_ws_kernel", "block_tail"), ("pack_tail_weights", "pack_weights"), ("mlp_kernel<true", "block_tail"), ("mlp_kernel", "mlp_fused"), ("attention_kernel", "attention"), ("pq_screen_kernel", "pq_assign"), ("pq_assign_kernel", "pq_assign"),
          ("pq_prep_codebook", "pq_prep"), ("gemm8_kernel<100,", "gemm_resid_ln(proj,fc2)"), ("gemm8_kernel<101,", "patch_gemm+pos+ln"),
          ("cls_rows_kernel", "patch_cls_rows"), ("probe_", "probes"), ("confusion_", "confusion"),
          ("layernorm_rowtile_kernel", "layernorm_tail(proj,fc2)"), ("layernorm_kernel", "layernorm"),
