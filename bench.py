@@ -162,8 +162,9 @@ def secondary_workloads(pkg, dev, res):
 
     def train_step():
         optim.zero_grad(set_to_none=True)
-        total, _o, _p, _f = trainee(img=img_t, aug_img=img_t, label=lab_t, img_pos=pos_t, it=it[0])
-        total.backward()
+        with torch.enable_grad():   # (the CPU-baseline leg switches autograd off globally)
+            total, _o, _p, _f = trainee(img=img_t, aug_img=img_t, label=lab_t, img_pos=pos_t, it=it[0])
+            total.backward()
         torch.nn.utils.clip_grad_norm_(trainee.model.parameters(), max_norm=10.0)
         optim.step()
         it[0] += 1

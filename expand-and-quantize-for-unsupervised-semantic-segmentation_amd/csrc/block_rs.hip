@@ -446,7 +446,7 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
     // 64 bytes (x) or 32 bytes (LayerNorm rows) in sixteen rows, and such stores leave a CU at a fraction of its store
     // rate.  Instead each 16-row group goes through a staging tile in the free hidden-tile space: the eight waves write
     // their columns, a barrier, then every wave instruction stores 1 KiB of consecutive memory.
-    constexpr int kXFirst = 5;   // row groups of the next tile's residual rows requested before the first store
+    constexpr int kXFirst = 4;   // row groups of the next tile's residual rows requested before the first store
     constexpr int kStgX = kStatS + NGMAX * 16 * 4 * 8, kRowX = C * 4 + 16, kStgL = kStgX + 16 * kRowX, kRowL = C * 2 + 16;
     static_assert(kStgL + 16 * kRowL <= kHs, "staging tiles must fit the hidden tile");
     const int l_ = olane(), fr = l_ & 15, fq = l_ >> 4, col0 = wave * WN + fq * 4;
@@ -487,18 +487,18 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
         RS_STAMP();   // (stores issued)
         lds_barrier();   // the staging tiles are free again
         RS_STAMP();
-        // (the last two groups of the next tile's residual rows go into the accumulator registers that two finished groups
+        // (the last groups of the next tile's residual rows go into the accumulator registers that as many finished groups
         // have left: all seven at once would not fit beside the accumulators)
-        if (rg == 1) request_x<kXFirst, NGMAX>(g, xr, next_row0, next_nrows, l_, wave);
+        if (rg == NGMAX - kXFirst - 1) request_x<kXFirst, NGMAX>(g, xr, next_row0, next_nrows, l_, wave);
     };
+    // (the next tile's residual rows are requested before the sums and the stores, into the registers of the G1
+    // accumulators and fragments)
+    request_x<0, kXFirst>(g, xr, next_row0, next_nrows, l_, wave);
     if (g.ln) {
-        // (the next tile's residual rows are requested between the sums and the stores, into the registers of the G1
-        // accumulators and fragments)
-        layer_norm(gamma_s, beta_s, [&] { request_x<0, kXFirst>(g, xr, next_row0, next_nrows, l_, wave); }, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
+        layer_norm(gamma_s, beta_s, [] {}, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
             *reinterpret_cast<uint2*>(hs + kStgL + fr * kRowL + (col0 + nt * 16) * 2) = uint2{lo, hi};
         }, group_out);
     } else {
-        request_x<0, kXFirst>(g, xr, next_row0, next_nrows, l_, wave);
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg)
             if (active(rg)) group_out(rg);

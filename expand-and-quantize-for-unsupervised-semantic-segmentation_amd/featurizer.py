@@ -7,6 +7,7 @@ runs patch embedding, the 12 blocks and the final norm as hand-written gfx950 ke
 fp32 accumulation and an fp32 residual stream.
 """
 import math
+import sys
 from functools import partial
 
 import torch
@@ -262,7 +263,7 @@ class DinoFeaturizer(nn.Module):
             # The reference downloads the DINO checkpoint here (dino_featurizer.py:48-51).  Fetching
             # is the caller's business on an air-gapped node: load a state_dict afterwards.
             print("No pretrained_weights given: backbone left at its random initialisation; "
-                  "load a DINO state_dict (same key names) before use.")
+                  "load a DINO state_dict (same key names) before use.", file=sys.stderr)
         self.n_feats = VIT_ARCH[arch][0]
 
     def train(self, mode: bool = True):
