@@ -485,6 +485,10 @@ int launch_inst(const Gemm8Args& g, hipStream_t s) {
     const int grid = ntiles < resident ? ntiles : resident;
     constexpr int ring = S * (BM + BN) * BK * 2;
     if (g.N > 4096) return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: N=%d exceeds the bias staging area", g.N);
+    // (the kernel addresses its operand pieces by 32-bit element offsets: every route into it is checked here)
+    if ((int64_t)g.M * g.lda >= (1LL << 32) || (int64_t)g.N * g.ldw >= (1LL << 32))
+        return equss::fail(EQUSS_E_UNSUPPORTED, "gemm8: M * lda = %lld or N * ldw = %lld elements exceed 32-bit operand offsets",
+                           (long long)g.M * g.lda, (long long)g.N * g.ldw);
     constexpr int extra = row_ln(EPI) ? (3 * BN * 4 + BM * WN * 8) : 16384;  // bias (+ gamma, beta, partial sums)
     static_assert(ring + extra <= 163840, "LDS budget");
     const int lds = ring + (row_ln(EPI) ? extra : g.N * 4);

@@ -198,13 +198,17 @@ class VisionTransformer(nn.Module):
             b = img.shape[0]
             feat = native.vit_forward_f32(self.device_handle(fp32=True), img, self._pos_for(h, w), keep_cls=True)
             return [feat.reshape(b, -1, self.embed_dim)], [], []
+        if self.precision == "fp32":
+            # (no silent change of precision: the fp32 parity forward keeps only the last block's features)
+            raise NotImplementedError("precision='fp32' returns the last block's features only (n=1); n > 1 runs in bf16")
         feats = native.vit_intermediate_feat(self.device_handle(), img, self._pos_for(h, w), n_last=n)
         return [feats[i] for i in range(n)], [], []
 
     @torch.no_grad()
     def residual_taps(self, x):
         """The fp32 residual stream after every block, (depth, B, 1+n_patches, C): for parity checks
-        against per-block reference outputs."""
+        against per-block reference outputs.  Always from the bf16 forward (bf16 GEMM operands, fp32 residual stream),
+        whatever ``precision`` says: the fp32 parity forward has no taps."""
         img = x.detach().to(torch.float32).contiguous()
         _, _, h, w = img.shape
         _feats, taps = native.vit_intermediate_feat(self.device_handle(), img, self._pos_for(h, w), n_last=1, want_taps=True)

@@ -113,7 +113,9 @@ int equss_pq_assign(const float* code, int64_t ld_code, const float* codebooks, 
                     void* stream);
 
 /* equss_pq_assign for callers that cannot allocate or own device memory beyond inputs and outputs
- * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  No counterpart
+ * (tight serving loops, harnesses that forbid hipMalloc, code that will run under HIP graph capture once one eager
+ * call per GPU has been made: the first call on a device resolves the buffer's address and raises the kernels' LDS
+ * limits, neither of which is a stream operation).  No counterpart
  * in the reference.  Same arguments, results and bits as equss_pq_assign minus the workspace: the
  * prepared codebooks and loss partials live in a buffer of equss_pq_static_scratch_bytes() (5 MiB) that
  * is part of the loaded library on every GPU.  Shapes whose equss_pq_workspace_bytes() exceeds it are

@@ -44,6 +44,20 @@ def test_workspace_queries_need_no_gpu(native):
     assert lib.equss_patch_workspace_bytes(2, 64, 64, 8, 384) > 0
 
 
+def test_fused_gemm_rejects_operands_beyond_32_bit_offsets(native):
+    """The large-tile GEMM kernel addresses its operand pieces by 32-bit element offsets.  Every route into it rejects a
+    strided operand whose M * lda (or N * ldw) does not fit, before anything is launched (so this needs no GPU): the fused
+    residual + LayerNorm entry point used to reach the kernel unchecked and would have read the wrong rows."""
+    import ctypes
+    lib = native.load_library()
+    fake = ctypes.c_void_p(1 << 20)   # non-null, aligned; never dereferenced: the call fails in argument checking
+    rc = lib.equss_gemm_resid_ln_bf16(fake, 65536, fake, 384, fake, fake, 384, fake, fake, fake, 384, 100000, 384, 384,
+                                      ctypes.c_float(1e-6), None)
+    assert rc == 3 and b"32-bit" in lib.equss_last_error()   # EQUSS_E_UNSUPPORTED
+    rc = lib.equss_gemm_bf16(fake, 65536, fake, 384, fake, fake, 1152, 100000, 1152, 384, 0, None)
+    assert rc == 3
+
+
 def test_state_dict_matches_reference_layout(pkg):
     for cfg, n_keys in ((pkg.configs.S_CFG, 167), (pkg.configs.B_CFG, 175)):
         m = pkg.build_model(cfg)
@@ -240,11 +254,21 @@ def test_no_register_is_used_while_an_lds_read_into_it_is_pending(pkg, tmp_path)
     bad = tmp_path / "bad.s"
     bad.write_text("\tds_read_b128 v[8:11], v1 offset:0\n\tv_accvgpr_write_b32 a3, v11\n\ts_waitcnt lgkmcnt(0)\n\tv_mov_b32_e32 v0, v8\n")
     assert chk.scan(str(bad)) == 1
+    # a scalar load pending on the same counter at a counted wait behind an inline-asm read, and such a read left pending
+    # where its block ends: each flagged once; the same with reads the compiler placed itself: not flagged
+    asm_read = "\t;;#ASMSTART\n\tds_read_b128 v[8:11], v1 offset:0\n\t;;#ASMEND\n"
+    bad.write_text(asm_read + "\tds_read_b128 v[12:15], v1 offset:16\n\ts_load_dword s4, s[0:1], 0x0\n\ts_waitcnt lgkmcnt(1)\n"
+                   "\tv_mov_b32_e32 v0, v8\n\ts_waitcnt lgkmcnt(0)\n")
+    assert chk.scan(str(bad)) == 1
+    bad.write_text(asm_read + "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt lgkmcnt(0)\n")
+    assert chk.scan(str(bad)) == 1
+    bad.write_text("\tds_read_b128 v[8:11], v1 offset:0\n\ts_load_dword s4, s[0:1], 0x0\n\ts_cbranch_scc1 .LBB0_1\n")
+    assert chk.scan(str(bad)) == 0
     import importlib
     build = importlib.import_module(pkg.__name__ + ".build")
     if not os.path.exists(build.HIPCC):
         pytest.skip("no hipcc here")
-    files = ["block_ws.hip", "mlp_fused.hip", "gemm_ws.hip", "gemm8_bf16.hip", "attention.hip"]
+    files = ["block_ws.hip", "mlp_fused.hip", "gemm_ws.hip", "gemm8_bf16.hip", "attention.hip", "block_rs.hip"]
 
     def flags_of(name):
         out = tmp_path / (name[:-4] + ".s")
