@@ -19,6 +19,7 @@
 //  * LayerNorm statistics keep the summation order of the 96-column waves of the other kernels: the even wave of a pair
 //    sums its three column groups and hands the running sums to the odd wave through LDS, which continues the chain.
 #include "equss_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -251,7 +252,7 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
     RS_STAMP();   // G0 done
     // LayerNorm of the rows in acc2 with scale / shift at gs / bs: fn(rg, nt, lo, hi) gets four bf16 as two dwords.
     // Per row the sums run over the column groups in the order of the 96-column layout (see the header).
-    auto layer_norm = [&](const float* gs, const float* bs, auto&& mid, auto&& fn, auto&& after_group) {
+    auto layer_norm = [&](const float* gs, const float* bs, auto all_first, auto&& fn, auto&& after_group) {
         // (lane numbers the compiler cannot see through: the scratch addresses are recomputed here, a few integer
         // instructions, instead of living in registers across the tile, where they would not fit beside the accumulators)
         const int lo_ = olane();
@@ -259,56 +260,78 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
         float2* const P = reinterpret_cast<float2*>(hs + kStatP);
         float2* const S = reinterpret_cast<float2*>(hs + kStatS);
         const int pair = wave >> 1;
-        auto chain = [&](int rg, float& s1, float& s2) {
+        // The running sums of the row groups advance together, column group by column group (per row the order of the
+        // additions is unchanged): one group after the other would be one long chain of dependent additions.
+        auto chains = [&](float (&s1)[NG], float (&s2)[NG]) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const f32x4 v = acc2[rg][nt];
-                s1 += (v.x + v.y) + (v.z + v.w);
-                s2 += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+#pragma unroll
+                for (int rg = 0; rg < NG; ++rg) {
+                    if (!active(rg)) continue;
+                    const f32x4 v = acc2[rg][nt];
+                    s1[rg] += (v.x + v.y) + (v.z + v.w);
+                    s2[rg] += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+                }
+                RS_PIN();
             }
         };
         if (!(wave & 1)) {
+            float s1[NG], s2[NG];
 #pragma unroll
-            for (int rg = 0; rg < NG; ++rg) {
-                if (!active(rg)) continue;
-                float s1 = 0.f, s2 = 0.f;
-                chain(rg, s1, s2);
-                P[(pair * 4 + fq) * (NGMAX * 16) + rg * 16 + fr] = make_float2(s1, s2);
-            }
+            for (int rg = 0; rg < NG; ++rg) { s1[rg] = 0.f; s2[rg] = 0.f; }
+            chains(s1, s2);
+#pragma unroll
+            for (int rg = 0; rg < NG; ++rg)
+                if (active(rg)) P[(pair * 4 + fq) * (NGMAX * 16) + rg * 16 + fr] = make_float2(s1[rg], s2[rg]);
         }
         RS_STAMP();   // (LayerNorm: first half of the sums)
         lds_barrier();
         RS_STAMP();
         if (wave & 1) {
+            float s1[NG], s2[NG];
 #pragma unroll
             for (int rg = 0; rg < NG; ++rg) {
-                if (!active(rg)) continue;
                 const float2 p = P[(pair * 4 + fq) * (NGMAX * 16) + rg * 16 + fr];
-                float s1 = p.x, s2 = p.y;
-                chain(rg, s1, s2);
-                // (__shfl_xor with its lane addresses built here: hoisted out of the tile loop they get spilled)
-                auto other = [&](float v, int mask) {
-                    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lo_ ^ mask) << 2, __builtin_bit_cast(int, v)));
-                };
-                s1 += other(s1, 16); s2 += other(s2, 16);
-                s1 += other(s1, 32); s2 += other(s2, 32);
-                if (fq == 0) S[(rg * 16 + fr) * 4 + pair] = make_float2(s1, s2);
+                s1[rg] = p.x; s2[rg] = p.y;
             }
+            chains(s1, s2);
+            // (__shfl_xor with its lane addresses built here: hoisted out of the tile loop they get spilled)
+            auto other = [&](float v, int mask) {
+                return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lo_ ^ mask) << 2, __builtin_bit_cast(int, v)));
+            };
+#pragma unroll
+            for (int rg = 0; rg < NG; ++rg) { s1[rg] += other(s1[rg], 16); s2[rg] += other(s2[rg], 16); }
+#pragma unroll
+            for (int rg = 0; rg < NG; ++rg) { s1[rg] += other(s1[rg], 32); s2[rg] += other(s2[rg], 32); }
+#pragma unroll
+            for (int rg = 0; rg < NG; ++rg)
+                if (active(rg) && fq == 0) S[(rg * 16 + fr) * 4 + pair] = make_float2(s1[rg], s2[rg]);
         }
         RS_STAMP();   // (LayerNorm: second half of the sums)
         lds_barrier();
         RS_STAMP();
-        mid();
-        // (row group by row group, scale and shift read again for each: seven means and seven scales kept across the loop
-        // would not fit beside the accumulators and the next tile's rows)
+        auto stats_of = [&](int rg, float& mean, float& rstd) {
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(S + (rg * 16 + fr) * 4);
+            const f32x4 q1 = *reinterpret_cast<const f32x4*>(S + (rg * 16 + fr) * 4 + 2);
+            mean = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
+            const float ex2 = ((q0.y + q0.w) + (q1.y + q1.w)) * (1.0f / C);
+            rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
+        };
+        // all_first: every group's mean and scale before the first row is normalised (the square roots and divisions of
+        // the groups overlap); otherwise group by group (the epilogue, where seven means and scales kept across the loop
+        // would not fit beside the accumulators and the next tile's rows).  Scale and shift are read again for each group.
+        constexpr bool ALL = decltype(all_first)::value;
+        float means[ALL ? NG : 1], rstds[ALL ? NG : 1];
+        if constexpr (ALL) {
+#pragma unroll
+            for (int rg = 0; rg < NG; ++rg) stats_of(rg, means[rg], rstds[rg]);
+        }
 #pragma unroll
         for (int rg = 0; rg < NG; ++rg) {
             if (!active(rg)) continue;
-            const f32x4 q0 = *reinterpret_cast<const f32x4*>(S + (rg * 16 + fr) * 4);
-            const f32x4 q1 = *reinterpret_cast<const f32x4*>(S + (rg * 16 + fr) * 4 + 2);
-            const float mean = ((q0.x + q0.z) + (q1.x + q1.z)) * (1.0f / C);
-            const float ex2 = ((q0.y + q0.w) + (q1.y + q1.w)) * (1.0f / C);
-            const float rstd = 1.0f / sqrtf(fmaxf(fmaf(-mean, mean, ex2), 0.f) + g.eps);
+            float mean, rstd;
+            if constexpr (ALL) { mean = means[rg]; rstd = rstds[rg]; }
+            else stats_of(rg, mean, rstd);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const f32x4 ga = *reinterpret_cast<const f32x4*>(gs + col0 + nt * 16);
@@ -332,7 +355,7 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
             const int col = col0 + nt * 16, kk = col & 31;   // slice col / 32, 16-byte piece kk / 8 of row fr, half (kk / 4) & 1
             ln2_off[nt] = (col >> 5) * (NGMAX * 1024) + ((kk >> 3) * 16 + fr) * 16 + ((kk >> 2) & 1) * 8;
         }
-        layer_norm(gamma2_s, beta2_s, [] {}, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
+        layer_norm(gamma2_s, beta2_s, std::true_type(), [&](int rg, int nt, uint32_t lo, uint32_t hi) {
             *reinterpret_cast<uint2*>(xs + ln2_off[nt] + rg * 1024) = uint2{lo, hi};
         }, [](int) {});
     }
@@ -495,7 +518,7 @@ __device__ __forceinline__ void rs_tile(const RsArgs& g, char* smem, L4 (&wr)[PD
     // accumulators and fragments)
     request_x<0, kXFirst>(g, xr, next_row0, next_nrows, l_, wave);
     if (g.ln) {
-        layer_norm(gamma_s, beta_s, [] {}, [&](int rg, int nt, uint32_t lo, uint32_t hi) {
+        layer_norm(gamma_s, beta_s, std::false_type(), [&](int rg, int nt, uint32_t lo, uint32_t hi) {
             *reinterpret_cast<uint2*>(hs + kStgL + fr * kRowL + (col0 + nt * 16) * 2) = uint2{lo, hi};
         }, group_out);
     } else {
