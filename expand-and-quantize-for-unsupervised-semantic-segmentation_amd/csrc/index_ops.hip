@@ -67,7 +67,37 @@ __global__ __launch_bounds__(256) void code_usage_kernel(const int64_t* __restri
         if (hist[k]) atomicAdd(&counts[(int64_t)p * K + k], (float)hist[k]);
 }
 
+// sums[p][k][:] += z[r, p*d : (p+1)*d] for every row r with idx[p][r] == k: the one_hot^T @ z of the EMA codebook update
+// (model/quantizer.py:485-491) without the (rows x K) one-hot matrix.  One wave per row and sub-space, a lane per column
+// (two passes for d = 128), float atomic adds into the K x d table of the sub-space: the additions of a codeword's rows
+// come in no fixed order, so the sums agree with the matrix product to rounding, not bit for bit.
+__global__ __launch_bounds__(256) void code_sums_kernel(const float* __restrict__ z, int64_t ld_z, const int64_t* __restrict__ idx,
+                                                        float* __restrict__ sums, int64_t rows, int K, int d) {
+    const int p = blockIdx.y, lane = threadIdx.x & 63;
+    const int64_t* src = idx + (int64_t)p * rows;
+    float* table = sums + (int64_t)p * K * d;
+    for (int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); r < rows; r += (int64_t)gridDim.x * 4) {
+        const int64_t k = src[r];
+        if (k < 0 || k >= K) continue;
+        const float* zr = z + r * ld_z + (int64_t)p * d;
+        for (int c = lane; c < d; c += 64) atomicAdd(&table[k * d + c], zr[c]);
+    }
+}
+
 }  // namespace
+
+extern "C" int equss_code_sums(const float* z, int64_t ld_z, const int64_t* idx, float* sums, int64_t rows, int num_pq, int K,
+                               int d, void* stream) {
+    if (!z || !idx || !sums) return equss::fail(EQUSS_E_NULL, "code_sums: null pointer argument");
+    if (rows < 0 || num_pq <= 0 || K <= 0 || d <= 0 || ld_z < (int64_t)num_pq * d)
+        return equss::fail(EQUSS_E_SHAPE, "code_sums: rows=%lld num_pq=%d K=%d d=%d ld_z=%lld", (long long)rows, num_pq, K, d, (long long)ld_z);
+    if (rows == 0) return EQUSS_OK;
+    int64_t gx = (rows + 3) / 4;
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(code_sums_kernel, dim3((unsigned)gx, num_pq), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), z, ld_z, idx,
+                       sums, rows, K, d);
+    return equss::check_launch("code_sums_kernel");
+}
 
 extern "C" int equss_index_rows_i16(const int64_t* z_index, const int64_t* label, int16_t* idx_rows, int16_t* lab_rows,
                                     int B, int h, int w, int H, int W, int num_pq, int upsample, void* stream) {

@@ -631,56 +631,74 @@ __global__ void pq_loss_reduce(const float* __restrict__ partial, float* __restr
     }
 }
 
-// softmax(-dist * inv_tau) over K for every (row, sub-space).  One workgroup per row tile of 4
-// rows; not on the timed path (the eval loop never consumes it), so plain fp32 VALU code.
+// softmax(-dist * inv_tau) over K for every (row, sub-space).  One workgroup per tile of 16 rows and sub-space: the
+// normalised rows wait in LDS, a thread owns codewords (tid, tid + 256, ...) and reads each of them once for all 16 rows
+// (a workgroup per row read the whole codebook of the sub-space for that one row), the distances of the tile go to LDS and
+// a wave per row turns them into probabilities.  Per (row, codeword) the dot product is the same fma chain as before.
+// Not on the timed path (the eval loop never consumes it), so plain fp32 VALU code.
+constexpr int kProbRows = 16;
 template <int D>
 __global__ __launch_bounds__(256) void pq_prob_kernel(const float* __restrict__ code, int64_t ld_code,
                                                       const float* __restrict__ cn,
                                                       const float* __restrict__ csq, float* __restrict__ prob,
-                                                      int rows, int num_pq, int K, int mode, float inv_tau) {
-    constexpr int LPR = D / 4;
+                                                      int rows, int num_pq, int K, int mode, float inv_tau, int rt) {
+    // (rt <= kProbRows rows per tile: fewer when K is large, so that the tile's distances fit 64 KiB of LDS)
+    constexpr int LPR = D / 4, RT = kProbRows;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* zn = reinterpret_cast<float*>(smem);  // D
-    float* dist = zn + D;                        // K
-    float* red = dist + K;                       // 4 maxima, 4 sums, row sum-of-squares
-    const int tid = threadIdx.x;
-    const int row = blockIdx.x, p = blockIdx.y;
-    if (tid < 64) {  // one wave normalises the row (LPR <= 32 lanes carry data)
+    float* zn = reinterpret_cast<float*>(smem);  // RT x D
+    float* arow = zn + RT * D;                   // RT: sum of squares of the normalised rows
+    float* dist = arow + RT;                     // rt x K
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * rt, p = blockIdx.y;
+    for (int r = wave; r < RT; r += 4) {   // one wave normalises a row (LPR <= 32 lanes carry data)
+        const int row = row0 + r < rows ? row0 + r : rows - 1;   // rows past the end repeat the last row; nothing of them is stored
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (tid < LPR) v = *reinterpret_cast<const f32x4*>(code + (size_t)row * ld_code + (size_t)p * D + 4 * tid);
+        if (lane < LPR) v = *reinterpret_cast<const f32x4*>(code + (size_t)row * ld_code + (size_t)p * D + 4 * lane);
         const float sa = normalize_row<D>(v, mode);
-        if (tid < LPR) *reinterpret_cast<f32x4*>(zn + 4 * tid) = v;
-        if (tid == 0) red[8] = sa;
+        if (lane < LPR) *reinterpret_cast<f32x4*>(zn + r * D + 4 * lane) = v;
+        if (lane == 0) arow[r] = sa;
     }
     __syncthreads();
-    const float arow = red[8];
-    float lmax = -__builtin_inff();
     for (int k = tid; k < K; k += 256) {
         const float* c = cn + ((size_t)p * K + k) * D;
-        float dot = 0.f;
-        for (int j = 0; j < D; ++j) dot = fmaf(zn[j], c[j], dot);
-        const float t0 = arow + csq[(size_t)p * K + k];
-        const float dd = -(t0 - 2.0f * dot) * inv_tau;
-        dist[k] = dd;
-        lmax = fmaxf(lmax, dd);
+        float dot[RT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) dot[r] = 0.f;
+        for (int j = 0; j < D; j += 4) {
+            const f32x4 c4 = *reinterpret_cast<const f32x4*>(c + j);
+#pragma unroll
+            for (int r = 0; r < RT; ++r) {
+                const f32x4 z4 = *reinterpret_cast<const f32x4*>(zn + r * D + j);   // (the same address in every lane: a broadcast)
+                dot[r] = fmaf(z4.x, c4.x, dot[r]);
+                dot[r] = fmaf(z4.y, c4.y, dot[r]);
+                dot[r] = fmaf(z4.z, c4.z, dot[r]);
+                dot[r] = fmaf(z4.w, c4.w, dot[r]);
+            }
+        }
+        const float ck = csq[(size_t)p * K + k];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const float t0 = arow[r] + ck;
+            if (r < rt) dist[r * K + k] = -(t0 - 2.0f * dot[r]) * inv_tau;
+        }
     }
-    lmax = equss::group_max<64>(lmax);
-    if ((tid & 63) == 0) red[tid >> 6] = lmax;
     __syncthreads();
-    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-    __syncthreads();
-    float lsum = 0.f;
-    for (int k = tid; k < K; k += 256) {
-        const float e = expf(dist[k] - m);
-        dist[k] = e;
-        lsum += e;
+    for (int r = wave; r < rt; r += 4) {
+        if (row0 + r >= rows) break;
+        float* dr = dist + r * K;
+        float m = -__builtin_inff();
+        for (int k = lane; k < K; k += 64) m = fmaxf(m, dr[k]);
+        m = equss::group_max<64>(m);
+        float lsum = 0.f;
+        for (int k = lane; k < K; k += 64) {
+            const float e = expf(dr[k] - m);
+            dr[k] = e;
+            lsum += e;
+        }
+        const float s = group_sum<64>(lsum);
+        float* out = prob + (size_t)(row0 + r) * num_pq * K + (size_t)p * K;
+        for (int k = lane; k < K; k += 64) out[k] = dr[k] / s;
     }
-    lsum = group_sum<64>(lsum);
-    if ((tid & 63) == 0) red[4 + (tid >> 6)] = lsum;
-    __syncthreads();
-    const float s = (red[4] + red[5]) + (red[6] + red[7]);
-    for (int k = tid; k < K; k += 256)
-        prob[(size_t)row * num_pq * K + (size_t)p * K + k] = dist[k] / s;
 }
 
 struct PqPlan { int NT, WK, WR, RT, R; };
@@ -948,23 +966,26 @@ extern "C" int equss_pq_prob(const float* code, int64_t ld_code, const float* co
     if (!prob) return equss::fail(EQUSS_E_NULL, "pq_prob: prob is null");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
     PqWorkspace w = carve(workspace, num_pq, K, d);
-    const size_t lds = ((size_t)d + K + 16) * 4;
+    int rt = (int)((60 * 1024 - ((size_t)kProbRows * d + kProbRows) * 4) / ((size_t)K * 4));
+    rt = rt > kProbRows ? kProbRows : (rt < 1 ? 1 : rt);
+    const size_t lds = ((size_t)kProbRows * d + kProbRows + (size_t)rt * K) * 4;
+    const unsigned prob_tiles = (unsigned)((rows + rt - 1) / rt);
     switch (d) {
         case 16:
             rc = launch_prep<16>(codebooks, w, num_pq * K, normalize, s);
-            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<16>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<16>, dim3(prob_tiles, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau, rt);
             break;
         case 32:
             rc = launch_prep<32>(codebooks, w, num_pq * K, normalize, s);
-            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<32>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<32>, dim3(prob_tiles, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau, rt);
             break;
         case 64:
             rc = launch_prep<64>(codebooks, w, num_pq * K, normalize, s);
-            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<64>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<64>, dim3(prob_tiles, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau, rt);
             break;
         default:
             rc = launch_prep<128>(codebooks, w, num_pq * K, normalize, s);
-            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<128>, dim3(rows, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau);
+            if (!rc) hipLaunchKernelGGL(pq_prob_kernel<128>, dim3(prob_tiles, num_pq), dim3(256), lds, s, code, ld_code, w.cn, w.csq, prob, rows, num_pq, K, normalize, inv_tau, rt);
             break;
     }
     if (rc) return rc;

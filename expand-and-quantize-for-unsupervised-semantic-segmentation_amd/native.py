@@ -28,7 +28,7 @@ EXPORTED_SYMBOLS = [
     "equss_layernorm_bf16", "equss_gemm_bf16", "equss_gemm_resid_ln_bf16", "equss_mlp_resid_ln_bf16", "equss_block_tail_bf16", "equss_attention_bf16",
     "equss_patch_workspace_bytes", "equss_patch_tokens",
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
-    "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images",
+    "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images", "equss_code_sums",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
     "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
     "equss_index_rows_i16", "equss_code_usage",
@@ -128,6 +128,8 @@ def _declare(lib):
     lib.equss_index_rows_i16.argtypes = [c_vp, c_vp, c_vp, c_vp, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
     lib.equss_code_usage.restype = c_int
     lib.equss_code_usage.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp]
+    lib.equss_code_sums.restype = c_int
+    lib.equss_code_sums.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
     lib.equss_probe_eval.restype = c_int
     lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
@@ -603,3 +605,17 @@ def code_usage(idx, num_codes, out=None):
         raise ValueError("code_usage: out must be a contiguous (num_pq, num_codes) float32 tensor")
     _check(load_library().equss_code_usage(_ptr(idx), _ptr(out), rows, num_pq, int(num_codes), _stream(idx)), "equss_code_usage")
     return out
+
+
+def code_sums(z, idx, num_codes, d):
+    """z (rows, num_pq*d) fp32, idx (num_pq, rows) int64 -> sums (num_pq, num_codes, d) fp32: per codeword the sum of the
+    rows assigned to it (the one_hot^T @ z of the EMA update, model/quantizer.py:485-491), all sub-spaces in one launch."""
+    _need_cuda(z, idx)
+    if idx.dtype != torch.int64 or idx.dim() != 2 or z.dtype != torch.float32 or z.dim() != 2 or z.stride(1) != 1:
+        raise ValueError("code_sums: z must be (rows, num_pq*d) float32 with unit column stride, idx (num_pq, rows) int64")
+    idx = idx.contiguous()
+    num_pq, rows = idx.shape
+    sums = torch.zeros((num_pq, num_codes, d), dtype=torch.float32, device=z.device)
+    _check(load_library().equss_code_sums(_ptr(z), z.stride(0), _ptr(idx), _ptr(sums), rows, num_pq, int(num_codes), int(d),
+                                          _stream(z)), "equss_code_sums")
+    return sums

@@ -20,20 +20,27 @@ _PQ_DIMS = (16, 32, 64, 128)
 
 
 @torch.no_grad()
+def _histogram_ranks(counts: torch.Tensor) -> torch.Tensor:
+    """counts (..., K) -> int64 (..., 3): for every count vector the first sorted rank at which the cumulative usage
+    reaches 10 / 50 / 90 % (-1 where it never does).  Device tensors in, device tensor out: no host transfer."""
+    prob = counts.float() / (counts.sum(dim=-1, keepdim=True) + 1)
+    prob, _ = torch.sort(prob, dim=-1, descending=True)
+    c_sum = torch.cumsum(prob, dim=-1)
+    thr = torch.tensor([0.1, 0.5, 0.9], device=c_sum.device, dtype=c_sum.dtype)
+    hit = c_sum.unsqueeze(-2) >= thr.unsqueeze(-1)                      # (..., 3, K)
+    return torch.where(hit.any(dim=-1), hit.float().argmax(dim=-1), torch.full_like(hit[..., 0], -1, dtype=torch.int64))
+
+
+def _histogram_dict(ranks, k: int, prefix: str) -> Dict:
+    return {f"{prefix}-{n}": (None if f < 0 else f / k) for n, f in zip(("p10", "p50", "p90"), ranks)}
+
+
+@torch.no_grad()
 def get_histogram_count(count: torch.Tensor, prefix: str = "") -> Dict:
     """quantizer.py:16-30: the sorted-rank fractions at which cumulative usage reaches 10/50/90 %.
     One sort + cumsum + three searches on the device and a single host transfer (the reference walks
     all K entries with three tensor comparisons each, i.e. 3 K host synchronisations on a GPU)."""
-    prob = count.float() / (count.sum() + 1)
-    k = len(prob)
-    prob, _ = torch.sort(prob, dim=0, descending=True)
-    c_sum = torch.cumsum(prob, dim=0)
-    thr = torch.tensor([0.1, 0.5, 0.9], device=c_sum.device, dtype=c_sum.dtype)
-    hit = (c_sum.unsqueeze(0) >= thr.unsqueeze(1))
-    first = torch.where(hit.any(dim=1), hit.float().argmax(dim=1), torch.full((3,), -1, device=c_sum.device))
-    first = first.tolist()
-    names = ("p10", "p50", "p90")
-    return {f"{prefix}-{n}": (None if f < 0 else f / k) for n, f in zip(names, first)}
+    return _histogram_dict(_histogram_ranks(count).tolist(), len(count), prefix)
 
 
 def _check_dim(d):
@@ -127,11 +134,12 @@ class VectorQuantizer(_RestartMixin, nn.Module):
             zq = zn + (emb - zn).detach()
         prob = native.pq_prob(rows.detach(), books.detach(), mode, 1.0)
         with torch.no_grad():
-            cur = torch.bincount(idx[0], minlength=self.num_codebook)
+            cur = native.code_usage(idx, self.num_codebook)[0]      # (whole numbers: exact in fp32)
             cur = all_reduce_tensor(cur, op="sum")  # also in eval, as the reference (:162)
             self.vq_count += cur
-            output.update(get_histogram_count(self.vq_count, prefix="total"))
-            output.update(get_histogram_count(cur, prefix="current"))
+            ranks = _histogram_ranks(torch.stack([self.vq_count, cur])).tolist()   # one host transfer for both
+            output.update(_histogram_dict(ranks[0], self.num_codebook, "total"))
+            output.update(_histogram_dict(ranks[1], self.num_codebook, "current"))
             if self.use_restart:
                 self.prepare_restart(cur, rows.detach())
         output["loss"] = codebook_loss + self.beta * commitment_loss
@@ -211,7 +219,6 @@ class EMAVectorQuantizer(_RestartMixin, nn.Module):
                 self.codebook.weight_avg.data.copy_(cent)
             self.need_initialized = False
         books = self.codebook.weight.unsqueeze(0)
-        output = dict()
         if not (torch.is_grad_enabled() and z.requires_grad):
             idx, zq, loss_sum = native.pq_assign(z.detach(), books, mode, gather_normalized=self.update_norm)
             commitment_loss = loss_sum[0] / float(n * d)
@@ -222,23 +229,43 @@ class EMAVectorQuantizer(_RestartMixin, nn.Module):
             commitment_loss = F.mse_loss(zn, emb.detach())
             zq = zn + (emb - zn).detach()
         prob = native.pq_prob(z.detach(), books, mode, 1.0)
+        output = dict()
         if self.training:
             with torch.no_grad():
-                one_hot = F.one_hot(idx[0], self.num_codebook).to(z.dtype)
-                cur = all_reduce_tensor(one_hot.sum(dim=0), op="sum")
-                cur_sum = all_reduce_tensor(one_hot.t() @ z.detach(), op="sum")
-                self.vq_count += cur
-                output.update(get_histogram_count(self.vq_count, prefix="total"))
-                output.update(get_histogram_count(cur, prefix="current"))
-                if self.use_restart:
-                    self.prepare_restart(cur, z.detach())
-                self.codebook.update(cur, cur_sum)
-                n_dead = int((cur == 0).sum())
-                output["codebook-usage"] = (self.num_codebook - n_dead) / self.num_codebook
+                cur, cur_sum = _usage_and_sums(z.detach(), idx, self.num_codebook, d)
+                ranks, n_dead = self._bookkeeping(cur[0], cur_sum[0], z.detach())
+                stats = torch.cat([ranks.reshape(-1), n_dead.reshape(1)]).tolist()   # the forward's one host transfer
+                output.update(_histogram_dict(stats[0:3], self.num_codebook, "total"))
+                output.update(_histogram_dict(stats[3:6], self.num_codebook, "current"))
+                output["codebook-usage"] = (self.num_codebook - stats[6]) / self.num_codebook
         output["loss"] = self.beta * commitment_loss
         output["commitment-loss"] = commitment_loss
         output["codebook-sum"] = torch.sum(torch.abs(self.codebook.weight))
         return zq, output, prob
+
+    @torch.no_grad()
+    def _bookkeeping(self, cur, cur_sum, z):
+        """Training-mode state update from this call's (already all-reduced) usage counts (K) and per-codeword sums (K, d):
+        quantizer.py:485-510.  Returns device tensors (no host transfer): histogram ranks (2, 3) and the number of
+        unused codewords."""
+        self.vq_count += cur
+        ranks = _histogram_ranks(torch.stack([self.vq_count, cur]))
+        if self.use_restart:
+            self.prepare_restart(cur, z)
+        self.codebook.update(cur, cur_sum)
+        return ranks, (cur == 0).sum()
+
+
+@torch.no_grad()
+def _usage_and_sums(z, idx, num_codebook, d):
+    """Usage counts (num_pq, K) and per-codeword sums of the assigned rows (num_pq, K, d) of one assign pass over
+    z (n, num_pq*d) with idx (num_pq, n), from two launches (integer histogram, scatter-add) instead of a dense
+    (n, K) one-hot matrix per sub-space, summed over the ranks with ONE all-reduce (the reference issues two per
+    sub-quantiser, quantizer.py:490-491)."""
+    cur = native.code_usage(idx, num_codebook)
+    cur_sum = native.code_sums(z, idx, num_codebook, d)
+    packed = all_reduce_tensor(torch.cat([cur.reshape(-1), cur_sum.reshape(-1)]), op="sum")
+    return packed[:cur.numel()].view_as(cur), packed[cur.numel():].view_as(cur_sum)
 
 
 class ProductQuantizerWrapper(nn.Module):
@@ -254,13 +281,29 @@ class ProductQuantizerWrapper(nn.Module):
             raise ValueError(f"Embed dim {embed_dim} should be divisible by #PQ {num_pq}.")
         self.num_pq = num_pq
         self.pq_dim = embed_dim // num_pq
+        self.batched = True   # False: always the reference's loop over the sub-quantisers (one set of launches each)
         self.quantizers = nn.ModuleList([
             quantizer_cls(num_codebook, self.pq_dim, beta=beta, normalize=normalize, decay=decay, eps=eps,
                           use_restart=use_restart, use_gumbel=use_gumbel, use_split=use_split,
                           use_weighted_sum=use_weighted_sum, update_norm=update_norm, need_initialized=need_initialized)
             for _ in range(self.num_pq)])
 
+    def _batched(self, z) -> bool:
+        """All sub-spaces in one launch: EMA quantisers of one configuration, no gradient into z, no pending
+        initialisation (the per-quantiser path handles those as the reference's loop does)."""
+        q0 = self.quantizers[0]
+        if not self.batched or not all(type(q) is EMAVectorQuantizer for q in self.quantizers):
+            return False
+        if torch.is_grad_enabled() and z.requires_grad:
+            return False
+        if any(q.training and q.need_initialized not in ("none", False) for q in self.quantizers):
+            return False
+        return z.is_cuda and all(q.normalize == q0.normalize and q.update_norm == q0.update_norm and q.beta == q0.beta and
+                                 q.training == q0.training for q in self.quantizers)
+
     def forward(self, z: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor], torch.Tensor]:
+        if self._batched(z):
+            return self._forward_batched(z)
         z_split = torch.chunk(z, chunks=self.num_pq, dim=1)
         z_quantized, probs, outputs = [], [], dict()
         for i in range(self.num_pq):
@@ -272,6 +315,47 @@ class ProductQuantizerWrapper(nn.Module):
         for k in outputs:
             outputs[k] = outputs[k] / self.num_pq
         return torch.cat(z_quantized, dim=1), outputs, torch.cat(probs, dim=-1)
+
+    def _forward_batched(self, z):
+        """quantizer.py:587-611 with the loop over sub-quantisers folded into the kernels: one assign launch and one
+        probability launch for all sub-spaces (they take (n, D) rows and (num_pq, K, d) codebooks as they are), one usage
+        histogram, one scatter-add and one all-reduce for the EMA statistics, one host transfer for every histogram."""
+        q0 = self.quantizers[0]
+        n, dim = z.shape
+        d, K, num_pq = self.pq_dim, q0.num_codebook, self.num_pq
+        _check_dim(d)
+        mode = _norm_mode(q0.normalize)
+        rows = z.detach()
+        books = torch.stack([q.codebook.weight for q in self.quantizers])
+        idx, zq, loss_sum = native.pq_assign(rows, books, mode, gather_normalized=q0.update_norm)
+        prob = native.pq_prob(rows, books, mode, 1.0)
+        commitment = loss_sum / float(n * d)                       # per sub-space
+        outputs = {}
+        if q0.training:
+            with torch.no_grad():
+                cur, cur_sum = _usage_and_sums(rows, idx, K, d)
+                z_split = torch.chunk(rows, chunks=num_pq, dim=1)
+                stats = []
+                for i, q in enumerate(self.quantizers):
+                    ranks, n_dead = q._bookkeeping(cur[i], cur_sum[i], z_split[i])
+                    stats.append(torch.cat([ranks.reshape(-1), n_dead.reshape(1)]))
+                stats = torch.stack(stats).tolist()                # the forward's one host transfer
+            for i in range(num_pq):                                # the mean over sub-quantisers, summed in the reference's order
+                out_i = dict(_histogram_dict(stats[i][0:3], K, "total"))
+                out_i.update(_histogram_dict(stats[i][3:6], K, "current"))
+                out_i["codebook-usage"] = (K - stats[i][6]) / K
+                for k, v in out_i.items():
+                    outputs[k] = v if i == 0 else outputs[k] + v
+            books = torch.stack([q.codebook.weight for q in self.quantizers])   # (the EMA update has changed them)
+        sums = books.abs().sum(dim=(1, 2))
+        for i in range(num_pq):
+            out_i = {"loss": q0.beta * commitment[i], "commitment-loss": commitment[i], "codebook-sum": sums[i]}
+            for k, v in out_i.items():
+                outputs[k] = v if (i == 0 or k not in outputs) else outputs[k] + v
+        for k in outputs:
+            outputs[k] = outputs[k] / num_pq
+        # prob comes out as (n, num_pq * K): the concatenation over sub-spaces the reference builds with torch.cat (:611)
+        return zq, outputs, prob
 
     def extra_repr(self) -> str:
         return f"num_pq={self.num_pq}"

@@ -340,6 +340,14 @@ int equss_index_rows_i16(const int64_t* z_index, const int64_t* label, int16_t* 
  *   of one pass).  Integer counting, so the result does not depend on scheduling.  K <= 8192. */
 int equss_code_usage(const int64_t* idx, float* counts, int64_t rows, int num_pq, int K, void* stream);
 
+/* Per-codeword sums of the rows assigned to it, for all sub-spaces in one launch: sums[p][k][:] += z[r, p*d:(p+1)*d] over
+ * the rows r with idx[p][r] == k -- the one_hot^T @ z of the EMA codebook update (model/quantizer.py:485-491), without the
+ * (rows x K) one-hot matrix.
+ *   z (rows, num_pq*d) fp32 with leading dimension ld_z; idx (num_pq, rows) int64; sums (num_pq, K, d) fp32, accumulated in
+ *   place (clear it first).  Float atomic adds: equal to the matrix product to rounding, not bit for bit. */
+int equss_code_sums(const float* z, int64_t ld_z, const int64_t* idx, float* sums, int64_t rows, int num_pq, int K, int d,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

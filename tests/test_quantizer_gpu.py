@@ -102,3 +102,45 @@ def test_quantizer_py_product_wrapper_matches_reference(pkg, golden, dev):
     # VectorQuantizer rejects the decay / eps arguments this wrapper passes, as in the reference (:579-585)
     with pytest.raises(TypeError):
         pkg.quantizer.ProductQuantizerWrapper(4, 32, 64, quantizer_cls=pkg.quantizer.VectorQuantizer)
+
+
+def test_product_wrapper_batched_path_equals_the_loop_over_quantisers(pkg, dev):
+    """quantizer.py:587-611 loops over the sub-quantisers; the wrapper here folds that loop into one assign launch, one
+    probability launch, one usage histogram, one scatter-add and one all-reduce.  Same outputs and the same EMA buffers
+    after two training steps and in eval mode (sums of a codeword's rows come in a different order: rounding only)."""
+    import copy
+    torch.manual_seed(11)
+    a = pkg.quantizer.ProductQuantizerWrapper(4, 64, 128, beta=0.25, normalize="l2", decay=0.9).to(dev).train()
+    for q in a.quantizers:
+        q.codebook.weight.normal_()
+        q.codebook.weight_avg.copy_(q.codebook.weight)
+    b = copy.deepcopy(a)
+    b.batched = False
+    for step in range(3):
+        if step == 2:
+            a.eval(); b.eval()
+        z = torch.randn(1000, 128, device=dev)
+        with torch.no_grad():
+            qa, oa, pa = a(z)
+            qb, ob, pb = b(z)
+        assert torch.allclose(qa, qb, rtol=0, atol=ATOL) and torch.allclose(pa, pb, rtol=1e-5, atol=1e-7)
+        assert sorted(oa.keys()) == sorted(ob.keys())
+        for k in oa:
+            assert abs(float(oa[k]) - float(ob[k])) <= 1e-6 + 1e-5 * abs(float(ob[k])), k
+        for x, y in zip(a.quantizers, b.quantizers):
+            assert torch.equal(x.vq_count, y.vq_count)
+            assert torch.allclose(x.codebook.vq_count, y.codebook.vq_count, rtol=1e-6)
+            assert torch.allclose(x.codebook.weight_avg, y.codebook.weight_avg, rtol=1e-5, atol=1e-6)
+            assert torch.allclose(x.codebook.weight, y.codebook.weight, rtol=1e-4, atol=1e-5)
+
+
+def test_code_sums_match_the_one_hot_product(native, dev):
+    """equss_code_sums against one_hot^T @ z (model/quantizer.py:485-491), two sub-spaces, a codeword nobody chose."""
+    torch.manual_seed(5)
+    z = torch.randn(777, 64, device=dev)
+    idx = torch.randint(0, 15, (2, 777), device=dev)   # codeword 15 stays unused
+    got = native.code_sums(z, idx, 16, 32)
+    for p in range(2):
+        want = torch.nn.functional.one_hot(idx[p], 16).float().t() @ z[:, p * 32:(p + 1) * 32]
+        assert torch.allclose(got[p], want, rtol=1e-5, atol=1e-5)
+    assert float(got[:, 15].abs().max()) == 0.0

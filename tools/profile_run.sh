@@ -2,11 +2,11 @@
 # One profiling round on the GPU box: kernel trace of the one-stream and of the default bench, then the two
 # PMC passes (FETCH_SIZE, WRITE_SIZE) each in a run of its own.  usage: tools/profile_run.sh <tag>
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 /root/repo/bench.py --steps 10 --warmup 3 --cpu-seconds 0"
+B="python3 /root/repo/bench.py --steps 10 --warmup 3 --cpu-seconds 0 --no-secondary"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --streams 1 > $OUT/trace.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- $B > $OUT/trace2.log 2>&1 || exit 1
 timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B --streams 1 --steps 5 > $OUT/fetch.log 2>&1 || exit 1
