@@ -17,6 +17,9 @@ pytestmark = pytest.mark.gpu
 # final features is ~5e-3; the bound leaves 4x headroom.
 FEAT_REL_L2 = 2e-2
 CODE_REL_L2 = 2e-2
+# ViT-B/8, 16 x 512 codewords, bf16 end to end against the fp32 reference: measured 0.9915 (13 of 1536 indices); a
+# flip needs two codewords closer than the bf16 error of the code.  The floor allows about twice as many.
+BCFG_INDEX_FLOOR = 0.98
 
 
 def _rel_l2(got, want):
@@ -232,6 +235,10 @@ def test_bcfg_vit_base_pq16x512(pkg, oracle, golden, dev):
     want_idx, gap = oracle.pq_top2_gap([b.cpu() for b in books], rows(code).cpu().contiguous(), "l2")
     assert_index_parity(z_index.reshape(16, -1).cpu().numpy(), want_idx.numpy(), gap.numpy(), "G11 own code")
     assert abs(float(outputs["vq-loss"]) - float(g["vq_loss"])) < 2e-2 * float(g["vq_loss"])
+    # end to end (bf16 backbone and head against the fp32 reference): the share of the 16 x 96 indices that agree
+    agree = float((z_index.reshape(16, -1).cpu().numpy() == g["index"].reshape(16, -1)).mean())
+    print("G11 end-to-end index agreement with the fp32 reference:", agree)
+    assert agree >= BCFG_INDEX_FLOOR, agree
 
 
 def test_training_head_matches_fp32_autograd(pkg, dev):
