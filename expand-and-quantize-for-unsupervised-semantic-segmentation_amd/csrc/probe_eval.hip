@@ -15,6 +15,15 @@
 //   probe_pixel_kernel  one wave per 8x8 block of output pixels: interpolates the 27+27 table
 //                       values and the norm, arg-max, cross-entropy, per-wave loss partials
 // followed by a fixed-order reduction of the partials (deterministic losses).
+//
+// Training the probes (train.py:80-97 with the probes' parameters in the optimiser): the same three kernels, the pixel
+// kernel in its GRAD form.  With T the table (low-resolution logits / inner products) the losses are functions of T only, and
+//     d(sum of cross-entropies) / dT[t][c]   = sum over pixels of  w_t(pixel) * (softmax(logit)[c] - [c == label])
+//     d(-sum of max cosines) / dT[t][32 + c] = sum over pixels of -w_t(pixel) * [c == arg-max] / |f_up|
+// (the arg-max and the norm are constants of the reference's graph too: one_hot(argmax), detached features), so the
+// kernel scatters those terms into a (rows, 64) gradient table: per wave through a small LDS window of the low-resolution
+// cells its 8x8 pixels touch, then one 256-byte atomic row add per cell.  The parameter gradients are table^T-shaped
+// products of that gradient table with the features, done by the caller.
 #include "equss_common.h"
 
 namespace {
@@ -145,6 +154,15 @@ __global__ __launch_bounds__(256) void probe_gram_kernel(const float* __restrict
     }
 }
 
+// Sum over the 16 lanes of a DPP row (quad swaps, half-row and row mirrors), in every lane of the row.
+__device__ __forceinline__ float row16_sum(float x) {
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, false));
+    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, false));
+    return x;
+}
+
 // Source index and weights of torch's bilinear up-sampling with align_corners = False
 // (F.interpolate, evaluator.py:54): src = scale * (dst + 0.5) - 0.5 clamped at 0, in fp32.
 __device__ __forceinline__ void bilinear_tap(int dst, float scale, int in_size, int& i0, int& step, float& w0, float& w1) {
@@ -162,19 +180,29 @@ struct ProbePixelArgs {
     int64_t* lin_pred;
     int64_t* clu_pred;
     float* norm_out;         // (B, H, W) |f_up| clamped at 1e-12, or null
+    float* grad;             // GRAD form: (B*h*w, 64) gradient table, zero on entry
     float* partial;          // (blocks, 4): ce sum, valid count, max-inner sum, unused
     int B, h, w, H, W, n_lin, n_clu;
     float scale_y, scale_x;
 };
 
 constexpr int kTilesPerWave = 2;
+constexpr int kWinCells = 16;      // GRAD form: low-resolution cells in a wave's LDS window (integer factor 8: 3 x 3)
 
 // One wave handles kTilesPerWave consecutive 8x8 blocks of output pixels (lane -> (lane/8, lane%8)).
 // With the usual integer up-sampling factor 8 the lanes of a wave share at most 2x2 low-res cells, so
 // the 16-byte table reads below are broadcasts served by a handful of cache lines.  Loss terms are
 // summed per lane over the tiles, then over the wave and the 4 waves of the block in a fixed order.
-__global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
+//
+// GRAD: the gradient terms of the header go into win[cell][class] with LDS atomics and the window is added to a.grad with one
+// atomic per cell and lane: 256 consecutive bytes per instruction.  LDS float atomics retire about one lane per three
+// cycles per CU whatever the addresses, so where the 16 pixels of a quadrant share their taps (integer factor 8) the
+// cross-entropy terms are first summed over the quadrant's DPP row: 4 lanes instead of 64 add each (class, tap).  A tile whose pixels touch more than kWinCells cells (down-sampling, factors
+// below 4) adds straight to memory.  The order of the atomic adds is not fixed: gradients agree to rounding, not bit for bit.
+template <bool GRAD>
+__global__ __launch_bounds__(256, GRAD ? 2 : 4) void probe_pixel_kernel(ProbePixelArgs a) {
     __shared__ float red[4][4];
+    __shared__ float win_s[GRAD ? 4 * kWinCells * kProbeSlots : 1];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int tiles_x = (a.W + 7) >> 3, tiles_y = (a.H + 7) >> 3;
@@ -185,7 +213,11 @@ __global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
         const int64_t tile = tile0 + it;
         if (tile >= n_tiles) break;
         const int tx = (int)(tile % tiles_x), ty = (int)((tile / tiles_x) % tiles_y), b = (int)(tile / ((int64_t)tiles_x * tiles_y));
-        const int X = tx * 8 + (lane & 7), Y = ty * 8 + (lane >> 3);
+        // lane -> pixel of the 8x8 tile: row-major; GRAD: quadrant-major (16 consecutive lanes = a 4x4 quadrant), because with
+        // the usual up-sampling factor 8 a quadrant's pixels share their four taps and their gradient terms can be summed
+        // over a 16-lane DPP row before they go to LDS
+        const int X = tx * 8 + (GRAD ? ((lane >> 4) & 1) * 4 + (lane & 3) : (lane & 7));
+        const int Y = ty * 8 + (GRAD ? (lane >> 5) * 4 + ((lane >> 2) & 3) : (lane >> 3));
         const bool live = X < a.W && Y < a.H;
         const int Xc = min(X, a.W - 1), Yc = min(Y, a.H - 1);
 
@@ -199,6 +231,46 @@ __global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
         const float* t11 = t10 + sx * kTableStride;
         const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
         const int64_t lab = live ? a.label[((int64_t)b * a.H + Yc) * a.W + Xc] : -1;
+
+        // GRAD: the window of cells this tile touches (taps grow with the pixel index: corners give the range)
+        float* win = win_s + wave * kWinCells * kProbeSlots;
+        int ymin = 0, xmin = 0, nx = 1, ncell = 0, j00 = 0, j01 = 0, j10 = 0, j11 = 0;
+        bool windowed = false;
+        if constexpr (GRAD) {
+            ymin = __shfl(y0, 0, 64); xmin = __shfl(x0, 0, 64);
+            const int ymax = __shfl(y0 + sy, 63, 64), xmax = __shfl(x0 + sx, 63, 64);
+            nx = xmax - xmin + 1;
+            ncell = nx * (ymax - ymin + 1);
+            windowed = ncell <= kWinCells;
+            if (windowed) {
+                for (int j = 0; j < ncell; ++j) win[j * kProbeSlots + lane] = 0.f;
+                j00 = ((y0 - ymin) * nx + (x0 - xmin)) * kProbeSlots;
+                j01 = j00 + sx * kProbeSlots; j10 = j00 + sy * nx * kProbeSlots; j11 = j10 + sx * kProbeSlots;
+            }
+        }
+        // do the 16 pixels of every quadrant share their taps?  (wave-uniform)
+        bool quads = false;
+        if constexpr (GRAD) {
+            if (windowed) {
+                const int lead = lane & 48;
+                const bool same = j00 == __shfl(j00, lead, 64) && sx == __shfl(sx, lead, 64) && sy == __shfl(sy, lead, 64);
+                quads = __builtin_amdgcn_ballot_w64(same) == ~0ull;
+            }
+        }
+        // one gradient term of this pixel, spread over its four taps
+        auto scatter = [&](int c, float v) {
+            if (windowed) {
+                atomicAdd(win + j00 + c, w00 * v); atomicAdd(win + j01 + c, w01 * v);
+                atomicAdd(win + j10 + c, w10 * v); atomicAdd(win + j11 + c, w11 * v);
+            } else {
+                float* g00 = a.grad + (t00 - a.table) / kTableStride * kProbeSlots;
+                float* g01 = a.grad + (t01 - a.table) / kTableStride * kProbeSlots;
+                float* g10 = a.grad + (t10 - a.table) / kTableStride * kProbeSlots;
+                float* g11 = a.grad + (t11 - a.table) / kTableStride * kProbeSlots;
+                atomicAdd(g00 + c, w00 * v); atomicAdd(g01 + c, w01 * v);
+                atomicAdd(g10 + c, w10 * v); atomicAdd(g11 + c, w11 * v);
+            }
+        };
 
         // ---- linear probe: interpolated logits, first arg-max, log-sum-exp ----------------------
         // (class slots beyond n_lin / n_clu hold kUnusedScore, so no masking is needed here)
@@ -226,6 +298,26 @@ __global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
         }
         acc_ce += valid ? (best + __logf(se)) - picked : 0.f;
         acc_n += valid ? 1.f : 0.f;
+        if constexpr (GRAD) {
+            const float rse = 1.0f / se;
+            if (quads) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c) {
+                    if (c >= a.n_lin) break;
+                    const float gterm = valid ? __expf(logit[c] - best) * rse - (c == (int)lab ? 1.f : 0.f) : 0.f;
+                    const float r00 = row16_sum(w00 * gterm), r01 = row16_sum(w01 * gterm);
+                    const float r10 = row16_sum(w10 * gterm), r11 = row16_sum(w11 * gterm);
+                    if ((lane & 15) == 0) {
+                        atomicAdd(win + j00 + c, r00); atomicAdd(win + j01 + c, r01);
+                        atomicAdd(win + j10 + c, r10); atomicAdd(win + j11 + c, r11);
+                    }
+                }
+            } else if (valid) {
+#pragma unroll
+                for (int c = 0; c < 32; ++c)
+                    if (c < a.n_lin) scatter(c, __expf(logit[c] - best) * rse - (c == (int)lab ? 1.f : 0.f));
+            }
+        }
 
         // ---- cluster probe: interpolated inner products, first arg-max, cosine of the maximum ----
         float cbest = kUnusedScore;
@@ -254,6 +346,16 @@ __global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
                      + w00 * w11 * q00[3] + w01 * w10 * a00);
         const float nrm = fmaxf(sqrtf(fmaxf(n2, 0.f)), 1e-12f);   // F.normalize eps (evaluator.py:96)
         acc_in += live ? cbest / nrm : 0.f;
+        if constexpr (GRAD) {
+            if (live) scatter(32 + cbest_i, -1.0f / nrm);
+            if (windowed) {
+                for (int j = 0; j < ncell; ++j) {
+                    const float v = win[j * kProbeSlots + lane];
+                    const int64_t cell = ((int64_t)b * a.h + ymin + j / nx) * a.w + xmin + j % nx;
+                    if (v != 0.f) atomicAdd(a.grad + cell * kProbeSlots + lane, v);
+                }
+            }
+        }
 
         if (live) {
             const int64_t o = ((int64_t)b * a.H + Y) * a.W + X;
@@ -279,7 +381,7 @@ __global__ __launch_bounds__(256, 4) void probe_pixel_kernel(ProbePixelArgs a) {
 // NaN when no pixel is labelled, as the reference's mean over an empty selection);
 // losses[1] = -mean over all pixels of the maximal cosine (evaluator.py:101-106 with alpha None).
 __global__ __launch_bounds__(256) void probe_loss_reduce(const float* __restrict__ partial, int64_t n, double pixels,
-                                                        float* __restrict__ losses) {
+                                                        float* __restrict__ losses, int n_losses) {
     __shared__ double red[3][256];
     double s[3] = {0.0, 0.0, 0.0};
     for (int64_t i = threadIdx.x; i < n; i += 256) {
@@ -298,6 +400,7 @@ __global__ __launch_bounds__(256) void probe_loss_reduce(const float* __restrict
     if (threadIdx.x == 0) {
         losses[0] = (float)(red[0][0] / red[1][0]);
         losses[1] = (float)(-red[2][0] / pixels);
+        if (n_losses > 2) losses[2] = (float)red[1][0];   // labelled pixels: what the cross-entropy gradients are divided by
     }
 }
 
@@ -333,11 +436,12 @@ extern "C" size_t equss_probe_workspace_bytes(int B, int h, int w, int H, int W)
     return table + align256(blocks * 4 * sizeof(float));
 }
 
-extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
-                                const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds,
-                                float* losses, float* feature_norm, void* workspace, size_t workspace_bytes,
-                                int B, int h, int w, int D, int H, int W, int n_linear, int n_cluster,
-                                void* stream) {
+namespace {
+int probe_impl(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
+               const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds,
+               float* losses, float* feature_norm, float* grad_table, void* workspace, size_t workspace_bytes,
+               int B, int h, int w, int D, int H, int W, int n_linear, int n_cluster,
+               void* stream) {
     if (!feat || !probes || !bias || !label || !linear_preds || !cluster_preds || !losses || !workspace)
         return equss::fail(EQUSS_E_NULL, "equss_probe_eval: null pointer argument");
     if (B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || D <= 0 || (D % 8) != 0)
@@ -368,7 +472,7 @@ extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float*
         if (rc) return rc;
     }
     ProbePixelArgs a;
-    a.table = table; a.label = label; a.lin_pred = linear_preds; a.clu_pred = cluster_preds; a.norm_out = feature_norm; a.partial = partial;
+    a.table = table; a.label = label; a.lin_pred = linear_preds; a.clu_pred = cluster_preds; a.norm_out = feature_norm; a.grad = grad_table; a.partial = partial;
     a.B = B; a.h = h; a.w = w; a.H = H; a.W = W; a.n_lin = n_linear; a.n_clu = n_cluster;
     a.scale_y = (float)h / (float)H;   // area_pixel_compute_scale of F.interpolate without scale_factor
     a.scale_x = (float)w / (float)W;
@@ -376,13 +480,40 @@ extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float*
     {
         equss::ProfScope ps(EQUSS_K_PROBE_PIXELS, s);
         const int64_t blocks = (tiles + 4 * kTilesPerWave - 1) / (4 * kTilesPerWave);
-        hipLaunchKernelGGL(probe_pixel_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        if (grad_table) {
+            if (hipMemsetAsync(grad_table, 0, (size_t)rows * kProbeSlots * sizeof(float), s) != hipSuccess)
+                return equss::fail(EQUSS_E_UNSUPPORTED, "equss_probe_train: cannot clear the gradient table");
+            hipLaunchKernelGGL(probe_pixel_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        } else {
+            hipLaunchKernelGGL(probe_pixel_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, a);
+        }
         rc = equss::check_launch("probe_pixel_kernel");
         if (rc) return rc;
-        hipLaunchKernelGGL(probe_loss_reduce, dim3(1), dim3(256), 0, s, partial, blocks, (double)B * H * W, losses);
+        hipLaunchKernelGGL(probe_loss_reduce, dim3(1), dim3(256), 0, s, partial, blocks, (double)B * H * W, losses, grad_table ? 3 : 2);
         rc = equss::check_launch("probe_loss_reduce");
     }
     return rc;
+}
+}  // namespace
+
+extern "C" int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
+                                const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds,
+                                float* losses, float* feature_norm, void* workspace, size_t workspace_bytes,
+                                int B, int h, int w, int D, int H, int W, int n_linear, int n_cluster,
+                                void* stream) {
+    return probe_impl(feat, ld_feat, probes, bias, label, linear_preds, cluster_preds, losses, feature_norm, nullptr, workspace,
+                      workspace_bytes, B, h, w, D, H, W, n_linear, n_cluster, stream);
+}
+
+extern "C" int equss_probe_train(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
+                                 const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds,
+                                 float* losses, float* grad_table, void* workspace, size_t workspace_bytes,
+                                 int B, int h, int w, int D, int H, int W, int n_linear, int n_cluster,
+                                 void* stream) {
+    if (!grad_table || ((uintptr_t)grad_table % 256) != 0)
+        return equss::fail(EQUSS_E_ALIGN, "equss_probe_train: grad_table must be a 256-byte aligned (B*h*w, 64) fp32 buffer");
+    return probe_impl(feat, ld_feat, probes, bias, label, linear_preds, cluster_preds, losses, nullptr, grad_table, workspace,
+                      workspace_bytes, B, h, w, D, H, W, n_linear, n_cluster, stream);
 }
 
 extern "C" int equss_confusion_update(const int64_t* preds, const int64_t* label, int64_t* confusion, int64_t n,

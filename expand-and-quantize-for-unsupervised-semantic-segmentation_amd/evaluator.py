@@ -19,6 +19,39 @@ from . import native
 __all__ = ["UnSegEvaluator", "ClusterLookup"]
 
 
+class _ProbeLosses(torch.autograd.Function):
+    """Both probe losses of evaluator.py:46-82 on a detached (rows, D) feature map, with the gradients of the probes'
+    parameters in closed form.  The forward is one pass of the HIP probe kernels that also leaves the gradients of the
+    loss sums with respect to the low-resolution class maps (``native.probe_train``); the parameter gradients are that
+    table's transpose times the features -- no (B, classes, H, W) tensor and no autograd graph over pixels:
+        d CE / d W = G_lin^T F / n_labelled      d CE / d b = column sums of G_lin / n_labelled
+        d cluster / d c^ = G_clu^T F / (B H W)   and through c^ = c / |c|:  d c = (d c^ - c^ <c^, d c^>) / |c|"""
+
+    @staticmethod
+    def forward(ctx, rows, weight, bias, clusters, label, b, h, w):
+        n_lin, n_clu = weight.shape[0], clusters.shape[0]
+        probes, pbias = native.pack_probes(weight.detach(), bias.detach(), clusters.detach())
+        lin, clu, losses, grad = native.probe_train(rows, probes, pbias, label, b, h, w, n_lin, n_clu)
+        ctx.save_for_backward(rows, grad, losses, clusters.detach(), probes)
+        ctx.meta = (n_lin, n_clu, int(label.numel()), weight.shape)
+        ctx.mark_non_differentiable(lin, clu)
+        return losses[0], losses[1], lin, clu
+
+    @staticmethod
+    def backward(ctx, g_lin, g_clu, _a, _b):
+        rows, grad, losses, clusters, probes = ctx.saved_tensors
+        n_lin, n_clu, pixels, wshape = ctx.meta
+        gt_f = torch.mm(grad.t(), rows)                      # (64, D): [linear rows ; cluster rows]
+        s_lin = g_lin / losses[2]
+        d_w = (gt_f[:n_lin] * s_lin).reshape(wshape)
+        d_b = grad[:, :n_lin].sum(0) * s_lin
+        chat = probes[native.PROBE_SLOTS:native.PROBE_SLOTS + n_clu]
+        d_chat = gt_f[native.PROBE_SLOTS:native.PROBE_SLOTS + n_clu] * (g_clu / float(pixels))
+        norm = clusters.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        d_c = (d_chat - chat * (chat * d_chat).sum(dim=1, keepdim=True)) / norm
+        return None, d_w, d_b, d_c, None, None, None, None
+
+
 class ClusterLookup(nn.Module):
     def __init__(self, dim: int, n_classes: int):
         super().__init__()
@@ -50,6 +83,7 @@ class UnSegEvaluator(nn.Module):
         self.linear_loss = nn.CrossEntropyLoss()
         self.slice_images = 4  # images per up-sampling slice of the stock-op path without a graph
         self.use_hip = True    # False forces the stock-op path (for comparisons)
+        self.hip_grads = True  # probes trained on a detached feature map: closed-form gradients from the HIP kernels
 
     def forward(self, out: torch.Tensor, img: torch.Tensor, label: Optional[torch.Tensor] = None,
                 is_crf: bool = False):
@@ -105,6 +139,12 @@ class UnSegEvaluator(nn.Module):
         applied at low resolution and their class maps interpolated; the per-pixel feature norm, which
         does not depend on the parameters, comes from the HIP probe kernel."""
         b, d, h, w = out.shape
+        if self.hip_grads and d % 8 == 0 and max(self.num_classes, self.cluster_probe.n_classes) <= native.PROBE_SLOTS:
+            lp = self.linear_probe
+            rows = out.detach().permute(0, 2, 3, 1).reshape(b * h * w, d).float()
+            linear_loss, cluster_loss, lin, clu = _ProbeLosses.apply(rows, lp.weight, lp.bias, self.cluster_probe.clusters,
+                                                                     label.long(), b, h, w)
+            return linear_loss, lin, cluster_loss, clu
         size = label.shape[-2:]
         same = (h, w) == tuple(size)
         up = (lambda t: t) if same else (lambda t: F.interpolate(t, size, mode="bilinear", align_corners=False))

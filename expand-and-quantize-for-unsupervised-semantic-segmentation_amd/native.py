@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
     "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images", "equss_code_sums",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
-    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_confusion_update",
+    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update",
     "equss_index_rows_i16", "equss_code_usage",
 ]
 
@@ -132,6 +132,9 @@ def _declare(lib):
     lib.equss_code_sums.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
     lib.equss_probe_eval.restype = c_int
     lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
+                                     c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
+    lib.equss_probe_train.restype = c_int
+    lib.equss_probe_train.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
 
 
@@ -554,6 +557,34 @@ def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster,
     if want_norm:
         return lin, clu, losses, norm
     return lin, clu, losses
+
+
+def probe_train(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster):
+    """probe_eval for the training pass: (linear_preds, cluster_preds, losses (3,), grad_table (batch*h*w, 64)):
+    losses = [linear CE, cluster loss, labelled pixels]; grad_table = gradients of the two loss sums with respect to
+    the low-resolution logits / inner products (see equss_probe_train in the header)."""
+    _need_cuda(feat_rows, probes, bias, label)
+    if feat_rows.dtype != torch.float32 or feat_rows.dim() != 2 or feat_rows.shape[0] != batch * h * w:
+        raise ValueError("probe_train: feat_rows must be (batch*h*w, D) float32")
+    if feat_rows.stride(1) != 1 or feat_rows.stride(0) % 4 or feat_rows.data_ptr() % 16:
+        feat_rows = feat_rows.contiguous()
+    if label.dtype != torch.int64 or label.dim() != 3 or label.shape[0] != batch:
+        raise ValueError("probe_train: label must be (batch, H, W) int64")
+    label = label.contiguous()
+    H, W = int(label.shape[1]), int(label.shape[2])
+    dev = feat_rows.device
+    lin = torch.empty((batch, H, W), dtype=torch.int64, device=dev)
+    clu = torch.empty((batch, H, W), dtype=torch.int64, device=dev)
+    losses = torch.empty(3, dtype=torch.float32, device=dev)
+    grad = torch.empty((batch * h * w, 2 * PROBE_SLOTS), dtype=torch.float32, device=dev)
+    lib = load_library()
+    nbytes = lib.equss_probe_workspace_bytes(batch, h, w, H, W)
+    ws = _workspace(dev, nbytes, "probe")
+    _check(lib.equss_probe_train(_ptr(feat_rows), feat_rows.stride(0), _ptr(probes), _ptr(bias), _ptr(label),
+                                 _ptr(lin), _ptr(clu), _ptr(losses), _ptr(grad), _ptr(ws), ws.numel(),
+                                 batch, h, w, feat_rows.shape[1], H, W, n_linear, n_cluster, _stream(feat_rows)),
+           "equss_probe_train")
+    return lin, clu, losses, grad
 
 
 def confusion_update(confusion, preds, label, num_classes):

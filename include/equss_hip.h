@@ -314,6 +314,23 @@ int equss_probe_eval(const float* feat, int64_t ld_feat, const float* probes, co
                      float* feature_norm, void* workspace, size_t workspace_bytes, int B, int h, int w, int D,
                      int H, int W, int n_linear, int n_cluster, void* stream);
 
+/* The same probes while they are trained (train.py:80-97 steps an optimiser over linear_probe.{weight,bias} and
+ * cluster_probe.clusters through the losses of model/evaluator.py:46-82 on a detached feature map): predictions and
+ * losses as equss_probe_eval, plus the gradients of the two loss SUMS with respect to the low-resolution table
+ *   T[t][c] = <feat[t], probes[c]> + bias[c]:
+ *   grad_table (B*h*w, 64) fp32 out, 256-byte aligned, cleared by the call:
+ *     [t][c], c < n_linear:          d(sum over labelled pixels of the cross-entropy) / dT[t][c]
+ *     [t][32 + c], c < n_cluster:    d(-sum over pixels of the maximal cosine) / dT[t][32 + c]  (arg-max and the pixel's
+ *                                    feature norm held constant, as one_hot(argmax) and the detached features are, :101-106)
+ *   losses (3) fp32 out: [0], [1] as equss_probe_eval, [2] the number of labelled pixels
+ * so that d linear_loss / d weight = (grad_table[:, :n]^T feat) / losses[2], d linear_loss / d bias = column sums / losses[2],
+ * d cluster_loss / d (normalised clusters) = (grad_table[:, 32:32+n']^T feat) / (B*H*W).  Atomic float adds: the gradient
+ * table agrees between calls to rounding, not bit for bit. */
+int equss_probe_train(const float* feat, int64_t ld_feat, const float* probes, const float* bias,
+                      const int64_t* label, int64_t* linear_preds, int64_t* cluster_preds, float* losses,
+                      float* grad_table, void* workspace, size_t workspace_bytes, int B, int h, int w, int D,
+                      int H, int W, int n_linear, int n_cluster, void* stream);
+
 /* Confusion-matrix accumulation of the eval loop: UnSegMetrics.update (model/metric.py:45-58).
  *   confusion (num_pred_classes, num_classes) int64, row-major, updated in place:
  *   confusion[pred, label] += 1 for every i < n with 0 <= label[i] < num_classes and

@@ -56,6 +56,43 @@ def test_probe_eval_contiguous_nchw_input_and_stock_path_agree(pkg, golden, dev)
     assert torch.allclose(hip[0], stock[0].detach(), rtol=2e-5) and torch.allclose(hip[2], stock[2].detach(), rtol=2e-5)
 
 
+@pytest.mark.parametrize("name", ["x8", "frac", "same", "down"])
+def test_probe_training_gradients_match_autograd(name, pkg, golden, dev):
+    """The probes' closed-form gradients from the HIP kernels (equss_probe_train: gradient table of the class maps, then
+    table^T x features) against torch autograd through the stock-op restatement of evaluator.py:46-82 (up-sampled class
+    maps, log-sum-exp cross-entropy, max cosine): losses, predictions and the gradients of linear_probe.weight / .bias and
+    cluster_probe.clusters.  'down' (label smaller than the feature map) takes the kernel's path without an LDS window."""
+    g = golden("g9_evaluator")
+    if name == "down":
+        b, d, h, w, hh, ww, ncls = 2, 64, 16, 12, 7, 5, 27
+        gen = torch.Generator(device="cpu").manual_seed(11)
+        out = torch.randn(b, d, h, w, generator=gen)
+        label = torch.randint(-1, ncls, (b, hh, ww), generator=gen)
+        ev = pkg.UnSegEvaluator(d, ncls, 0).to(dev)
+    else:
+        out, label, sd = regen_probe_case(g[f"{name}_meta"], g[f"{name}_seed"])
+        b, d, h, w, hh, ww, ncls = (int(v) for v in g[f"{name}_meta"])
+        ev = _evaluator(pkg, sd, d, ncls, dev)
+    ev.train()
+    params = [ev.linear_probe.weight, ev.linear_probe.bias, ev.cluster_probe.clusters]
+    res = {}
+    for hip in (True, False):
+        ev.hip_grads = hip
+        lin_loss, lin_p, clu_loss, clu_p = ev(out.to(dev), None, label=label.to(dev))
+        grads = torch.autograd.grad(0.7 * lin_loss + 1.3 * clu_loss, params)
+        res[hip] = (lin_loss.detach(), clu_loss.detach(), lin_p, clu_p, grads)
+    torch.cuda.synchronize()
+    a, r = res[True], res[False]
+    assert torch.allclose(a[0], r[0], rtol=2e-5) and torch.allclose(a[1], r[1], rtol=2e-5)
+    assert float((a[2] != r[2]).float().mean()) < 1e-3 and float((a[3] != r[3]).float().mean()) < 1e-3   # near-ties only
+    for pname, ga, gr in zip(("weight", "bias", "clusters"), a[4], r[4]):
+        assert ga.shape == gr.shape, pname
+        err = float((ga - gr).norm() / gr.norm())
+        print(name, pname, "gradient rel-L2 error", err)
+        # (a pixel whose two best cosines tie to ~1e-7 may pick the other class in the two evaluation orders)
+        assert err < (2e-3 if pname == "clusters" else 2e-5), (pname, err)
+
+
 def test_probe_eval_no_labelled_pixel_gives_nan_loss(pkg, golden, dev):
     g = golden("g9_evaluator")
     out, label, sd = regen_probe_case(g["same_meta"], g["same_seed"])
