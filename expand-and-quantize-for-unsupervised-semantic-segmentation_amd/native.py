@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
     "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images", "equss_code_sums",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
-    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update",
+    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update", "equss_pq_st_backward",
     "equss_index_rows_i16", "equss_code_usage",
 ]
 
@@ -130,6 +130,9 @@ def _declare(lib):
     lib.equss_code_usage.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp]
     lib.equss_code_sums.restype = c_int
     lib.equss_code_sums.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
+    lib.equss_pq_st_backward.restype = c_int
+    lib.equss_pq_st_backward.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, ctypes.c_float, ctypes.c_float,
+                                         c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp]
     lib.equss_probe_eval.restype = c_int
     lib.equss_probe_eval.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_sz,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_vp]
@@ -557,6 +560,33 @@ def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster,
     if want_norm:
         return lin, clu, losses, norm
     return lin, clu, losses
+
+
+def pq_st_backward(rows, emb, idx, g_zq, g_vq, beta, book, num_codes, d, want_rows=True, want_books=True):
+    """Gradients of the training-pass quantisation (see equss_pq_st_backward in the header): rows / emb / g_zq
+    (n, num_pq*d) fp32, idx (num_pq, n) int64, g_vq a 0-dim fp32 tensor -> (g_rows or None, g_books (num_pq, K, d) or None)."""
+    _need_cuda(rows, emb, idx, g_vq)
+    n, cols = rows.shape
+    num_pq = cols // d
+
+    def row_major(t):
+        if t is None:
+            return None
+        t = t.float()
+        if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            t = t.contiguous()
+        return t
+    rows, emb, g_zq = row_major(rows), row_major(emb), row_major(g_zq)
+    idx = idx.contiguous()
+    g_vq = g_vq.reshape(1).float().contiguous()
+    g_rows = torch.empty((n, cols), dtype=torch.float32, device=rows.device) if want_rows else None
+    g_books = torch.empty((num_pq, num_codes, d), dtype=torch.float32, device=rows.device) if want_books else None
+    lib = load_library()
+    _check(lib.equss_pq_st_backward(_ptr(rows), rows.stride(0), _ptr(emb), emb.stride(0), _ptr(idx), _ptr(g_zq),
+                                    g_zq.stride(0) if g_zq is not None else 0, _ptr(g_vq), float(beta), float(book),
+                                    _ptr(g_rows), g_rows.stride(0) if want_rows else 0, _ptr(g_books), n, num_pq,
+                                    num_codes, d, _stream(rows)), "equss_pq_st_backward")
+    return g_rows, g_books
 
 
 def probe_train(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster):

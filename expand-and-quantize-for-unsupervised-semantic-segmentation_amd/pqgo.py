@@ -218,8 +218,8 @@ class _PQStraightThrough(torch.autograd.Function):
         zn = z / |z| ;  emb = books[idx] ;  vq = mean_p(book * mse(emb, zn.detach()) + beta * mse(zn, emb.detach()))
         zq = zn + (emb - zn).detach()
     Forward = the eval path's HIP kernel (indices, gathered rows, squared-error sums in one pass);
-    backward = the closed form, a handful of elementwise passes and ONE index_add into the codebooks,
-    instead of autograd through ~15 elementwise ops on (rows, D) tensors:
+    backward = the closed form in one HIP pass over the rows (``native.pq_st_backward``: z, emb and g_zq read once,
+    d z written once, d books by atomic adds) instead of autograd through ~15 elementwise ops on (rows, D) tensors:
         d zn   = g_zq + g_vq * 2 beta (zn - emb) / (n d P)          d z = (d zn - zn <zn, d zn>) / |z|
         d emb  = g_vq * 2 book (emb - zn) / (n d P)                  d books[p, k] = sum over rows with idx = k
     Returns (zq rows, vq-loss, idx)."""
@@ -235,11 +235,19 @@ class _PQStraightThrough(torch.autograd.Function):
         ctx.mark_non_differentiable(idx)
         return emb, vq, idx
 
+    hip_backward = True   # False: the closed form below with stock elementwise ops and index_add_ (for comparisons)
+
     @staticmethod
     def backward(ctx, g_zq, g_vq, _g_idx):
         rows, emb, idx = ctx.saved_tensors
         num_pq, k, d, beta, book = ctx.meta
         n = rows.shape[0]
+        if _PQStraightThrough.hip_backward:
+            if g_vq is None:
+                g_vq = torch.zeros((), dtype=torch.float32, device=rows.device)
+            g_rows, g_books = native.pq_st_backward(rows, emb, idx, g_zq, g_vq, beta, book, k, d,
+                                                    want_rows=ctx.needs_input_grad[0], want_books=ctx.needs_input_grad[1])
+            return g_rows, g_books, None, None
         z3 = rows.reshape(n, num_pq, d)
         norm = z3.norm(dim=-1, keepdim=True).clamp_min(1e-12)     # F.normalize's eps
         zn = z3 / norm

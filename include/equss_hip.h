@@ -357,6 +357,23 @@ int equss_index_rows_i16(const int64_t* z_index, const int64_t* label, int16_t* 
  *   of one pass).  Integer counting, so the result does not depend on scheduling.  K <= 8192. */
 int equss_code_usage(const int64_t* idx, float* counts, int64_t rows, int num_pq, int K, void* stream);
 
+/* Backward of the training-pass quantisation (model/dino_pqgo.py:613-690 under autograd: l2-normalised codes, raw
+ * codeword gather, vq = mean_p(book * mse(emb, zn.detach()) + beta * mse(zn, emb.detach())), zq = zn + (emb - zn).detach()),
+ * all sub-spaces in one pass over the rows:
+ *   z      (rows, num_pq*d) fp32: the codes the forward quantised (before normalisation), leading dimension ld_z
+ *   emb    (rows, num_pq*d) fp32: the gathered codewords the forward returned (equss_pq_assign's zq with
+ *          gather_normalized = 0 and no straight-through arithmetic, i.e. books[idx])
+ *   idx    (num_pq, rows) int64
+ *   g_zq   (rows, num_pq*d) fp32 gradient of the quantised output, or NULL for zero
+ *   g_vq   one fp32 on the device: gradient of the vq loss
+ *   g_z    (rows, num_pq*d) fp32 out or NULL: gradient of z
+ *   g_books (num_pq, K, d) fp32 out or NULL: gradient of the codebooks, cleared by the call, accumulated with float
+ *          atomics (agrees between calls to rounding, not bit for bit)
+ * d in {16, 32, 64, 128}; row buffers 16-byte aligned, leading dimensions multiples of 4. */
+int equss_pq_st_backward(const float* z, int64_t ld_z, const float* emb, int64_t ld_emb, const int64_t* idx,
+                         const float* g_zq, int64_t ld_g, const float* g_vq, float beta, float book,
+                         float* g_z, int64_t ld_gz, float* g_books, int rows, int num_pq, int K, int d, void* stream);
+
 /* Per-codeword sums of the rows assigned to it, for all sub-spaces in one launch: sums[p][k][:] += z[r, p*d:(p+1)*d] over
  * the rows r with idx[p][r] == k -- the one_hot^T @ z of the EMA codebook update (model/quantizer.py:485-491), without the
  * (rows x K) one-hot matrix.

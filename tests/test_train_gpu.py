@@ -121,6 +121,33 @@ def test_training_step_under_autocast_and_gradscaler(pkg, golden, dev):
     assert not torch.equal(code_a, code_b)
 
 
+@pytest.mark.parametrize("num_pq,k,d,n", [(8, 256, 128, 3001), (4, 64, 16, 517), (3, 32, 64, 130), (16, 512, 128, 700)])
+def test_pq_straight_through_backward_kernel_matches_the_closed_form(num_pq, k, d, n, pkg, dev):
+    """equss_pq_st_backward (one pass over the rows, atomic adds into the codebook gradient) against the same closed
+    form written with stock elementwise ops and index_add_ (dino_pqgo.py:613-690 differentiated by hand), with and
+    without a gradient arriving through the quantised output; widths where a wave covers several rows' worth of
+    sub-spaces (d = 16) and where the row is not a multiple of 256 floats (3 x 64)."""
+    torch.manual_seed(3)
+    st = pkg.pqgo._PQStraightThrough
+    rows = torch.randn(n, num_pq * d, device=dev, requires_grad=True)
+    books = ((torch.rand(num_pq, k, d, device=dev) - 0.5) * 0.2).requires_grad_(True)
+    g = torch.randn(n, num_pq * d, device=dev) * 1e-3
+    res = {}
+    for hip in (True, False):
+        st.hip_backward = hip
+        try:
+            zq, vq, idx = st.apply(rows, books, 0.25, 1.0)
+            both = torch.autograd.grad([zq, vq], [rows, books], [g, torch.tensor(0.7, device=dev)], retain_graph=True)
+            only_vq = torch.autograd.grad(vq, [rows, books])
+        finally:
+            st.hip_backward = True
+        res[hip] = both + only_vq
+    for name, a, b in zip(("rows", "books", "rows (vq only)", "books (vq only)"), res[True], res[False]):
+        err = float((a - b).norm() / b.norm())
+        print(num_pq, k, d, name, "rel-L2", err)
+        assert a.shape == b.shape and err < 1e-5, (name, err)
+
+
 def test_eval_caches_follow_codebook_restart(pkg, dev):
     """An eval forward builds the cached codebook stack; restart() then replaces codewords in place; the
     next eval forward must assign with the new codebook, with no optimiser step in between."""
