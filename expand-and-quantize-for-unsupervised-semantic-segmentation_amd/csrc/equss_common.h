@@ -156,7 +156,17 @@ __device__ __forceinline__ lds_u32x4 lds_load_b128_at(uint32_t addr) {
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
+// (the transposing 8-byte load of gfx950: lane l of a 16-lane group gets column l of the 4 x 16 block of 16-bit elements
+// whose four rows the group's lanes address, four lanes per row)
+typedef uint32_t lds_u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ lds_u32x2 lds_load_tr16_b64_at(uint32_t addr) {
+    lds_u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
 __device__ __forceinline__ void lds_tie(lds_u32x4& d) { asm volatile("" : "+v"(d)); }
+__device__ __forceinline__ void lds_tie(lds_u32x2& d) { asm volatile("" : "+v"(d)); }
 template <int N, typename... R>
 __device__ __forceinline__ void lds_wait_for(R&... d) {
     __builtin_amdgcn_sched_barrier(0);   // (what was written before the wait stays before it: MFMAs would sink below it)

@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
     "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images", "equss_code_sums",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
-    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update", "equss_pq_st_backward",
+    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update", "equss_pq_st_backward", "equss_gemm_tn_bf16",
     "equss_index_rows_i16", "equss_code_usage",
 ]
 
@@ -130,6 +130,8 @@ def _declare(lib):
     lib.equss_code_usage.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp]
     lib.equss_code_sums.restype = c_int
     lib.equss_code_sums.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
+    lib.equss_gemm_tn_bf16.restype = c_int
+    lib.equss_gemm_tn_bf16.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp]
     lib.equss_pq_st_backward.restype = c_int
     lib.equss_pq_st_backward.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, ctypes.c_float, ctypes.c_float,
                                          c_vp, c_i64, c_vp, c_int, c_int, c_int, c_int, c_vp]
@@ -560,6 +562,22 @@ def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster,
     if want_norm:
         return lin, clu, losses, norm
     return lin, clu, losses
+
+
+def gemm_tn_bf16(a, b):
+    """a (rows, M) bf16, b (rows, N) bf16 (row-major, unit column stride) -> a^T b (M, N) fp32: the weight-gradient
+    product of the training pass, summed over the rows on the matrix cores."""
+    _need_cuda(a, b)
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.dim() != 2 or b.dim() != 2 or a.shape[0] != b.shape[0]:
+        raise ValueError("gemm_tn_bf16: a (rows, M) and b (rows, N) must be bfloat16 with equal row counts")
+
+    def usable(t):
+        return t if (t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0) else t.contiguous()
+    a, b = usable(a), usable(b)
+    out = torch.empty((a.shape[1], b.shape[1]), dtype=torch.float32, device=a.device)
+    _check(load_library().equss_gemm_tn_bf16(_ptr(a), a.stride(0), _ptr(b), b.stride(0), _ptr(out), out.stride(0),
+                                             a.shape[0], a.shape[1], b.shape[1], _stream(a)), "equss_gemm_tn_bf16")
+    return out
 
 
 def pq_st_backward(rows, emb, idx, g_zq, g_vq, beta, book, num_codes, d, want_rows=True, want_books=True):

@@ -158,7 +158,8 @@ class STEGOLoss(nn.Module):
 class _HeadFunction(torch.autograd.Function):
     """cluster1(f) + cluster2(f) on token-major rows: forward through the same HIP head GEMMs as the
     eval path (bf16 operands, fp32 accumulation and output), backward as bf16 GEMMs with fp32
-    accumulation -- the precision class of the reference's training pass, which runs these
+    accumulation on the HIP kernels (``native.gemm_tn_bf16`` for the weight gradients, ``native.gemm_bf16`` for the
+    gradient through the second branch) -- the precision class of the reference's training pass, which runs these
     convolutions under fp16 autocast (train.py:80).  The frozen backbone needs no input gradient.
     The HIP forward leaves [f | relu(W2a f + b2a)] behind in bf16, which is what the backward needs."""
 
@@ -175,15 +176,24 @@ class _HeadFunction(torch.autograd.Function):
         ctx.shapes = (w1.shape, w2a.shape, w2b.shape)
         return code
 
+    native_backward = True   # False: the same products as torch.mm calls (for comparisons)
+
     @staticmethod
     def backward(ctx, g):
         fh, w_cat = ctx.saved_tensors
         c = fh.shape[1] // 2
+        d = w_cat.shape[0]
         s1, s2a, s2b = ctx.shapes
         g_bf = g.to(torch.bfloat16)
-        dw_cat = torch.mm(g_bf.t(), fh).float()                  # (D, 2C) = [dW1 | dW2b]
-        d_pre = torch.mm(g_bf, w_cat[:, c:]) * (fh[:, c:] > 0)   # through the ReLU
-        dw2a = torch.mm(d_pre.t(), fh[:, :c]).float()
+        if _HeadFunction.native_backward and c % 128 == 0 and d % 128 == 0:
+            # dW = g^T f sums over batch * tokens: the split-K transposed-operand kernel; d_pre is an ordinary A W^T GEMM
+            dw_cat = native.gemm_tn_bf16(g_bf, fh)                   # (D, 2C) = [dW1 | dW2b]
+            d_pre = native.gemm_bf16(g_bf, w_cat[:, c:].t().contiguous(), None, native.EPI_BF16) * (fh[:, c:] > 0)
+            dw2a = native.gemm_tn_bf16(d_pre, fh[:, :c])
+        else:
+            dw_cat = torch.mm(g_bf.t(), fh).float()                  # (D, 2C) = [dW1 | dW2b]
+            d_pre = torch.mm(g_bf, w_cat[:, c:]) * (fh[:, c:] > 0)   # through the ReLU
+            dw2a = torch.mm(d_pre.t(), fh[:, :c]).float()
         db = g.sum(0)
         return (None, dw_cat[:, :c].reshape(s1), db, dw2a.reshape(s2a), d_pre.float().sum(0),
                 dw_cat[:, c:].reshape(s2b), db)

@@ -357,6 +357,15 @@ int equss_index_rows_i16(const int64_t* z_index, const int64_t* label, int16_t* 
  *   of one pass).  Integer counting, so the result does not depend on scheduling.  K <= 8192. */
 int equss_code_usage(const int64_t* idx, float* counts, int64_t rows, int num_pq, int K, void* stream);
 
+/* Weight gradient of a 1x1 convolution / nn.Linear in the training pass (the backward of model/dino_pqgo.py:104-112:
+ * dW = g^T f, summed over batch * tokens): C[m][n] = sum over r < rows of A[r][m] * B[r][n].
+ *   A (rows, M) bf16, B (rows, N) bf16, row-major, leading dimensions multiples of 8, 16-byte aligned
+ *   C (M, N) fp32 out, leading dimension ldc, cleared by the call
+ * M and N multiples of 128.  bf16 MFMA, fp32 accumulation; the row range is split over workgroups that add their tiles
+ * with float atomics, so C agrees between calls to rounding, not bit for bit. */
+int equss_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc,
+                       int rows, int M, int N, void* stream);
+
 /* Backward of the training-pass quantisation (model/dino_pqgo.py:613-690 under autograd: l2-normalised codes, raw
  * codeword gather, vq = mean_p(book * mse(emb, zn.detach()) + beta * mse(zn, emb.detach())), zq = zn + (emb - zn).detach()),
  * all sub-spaces in one pass over the rows:

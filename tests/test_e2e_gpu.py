@@ -268,6 +268,28 @@ def test_training_head_matches_fp32_autograd(pkg, dev):
     assert max(errs.values()) < 5e-2, errs
 
 
+@pytest.mark.parametrize("rows,m,n", [(1000, 128, 128), (4099, 384, 256), (102400, 1024, 768), (31, 128, 384)])
+def test_transposed_operand_gemm_matches_fp64(rows, m, n, native, dev):
+    """equss_gemm_tn_bf16 (C = A^T B summed over the rows, split over workgroups, operands through the transposing
+    LDS read) against the fp64 product of the same bf16 operands: row counts that are no multiple of the 32-row K
+    step or of the split, a strided B, and the head's weight-gradient shape at the benchmark size."""
+    gen = torch.Generator(device="cpu").manual_seed(rows)
+    a = torch.randn(rows, m, generator=gen).to(torch.bfloat16).to(dev)
+    b_full = torch.randn(rows, n + 64, generator=gen).to(torch.bfloat16).to(dev)
+    b = b_full[:, 64:] if rows < 50000 else b_full[:, :n]
+    got = native.gemm_tn_bf16(a, b)
+    if rows > 50000:   # fp64 of the whole product is slow: a slice of the output
+        want = (a[:, :256].double().t() @ b[:, :128].double()).float()
+        got = got[:256, :128]
+    else:
+        want = (a.double().t() @ b.double()).float()
+    err = float((got - want).abs().max()) / float(want.abs().max())
+    print(rows, m, n, "max error relative to the largest entry", err)
+    assert got.shape == want.shape and err < 2e-6 * max(1.0, (rows / 1000.0) ** 0.5)
+    with pytest.raises(ValueError):      # M must be a multiple of 128
+        native.gemm_tn_bf16(a[:, :96].contiguous(), b)
+
+
 def test_eval_loop_miou_parity(wrapper, pkg, oracle, dev):
     """The eval loop of train.py:259-364 / eval.py:60-110 on a small synthetic set (two batches of two
     320 x 320 images): wrapper forward -> UnSegMetrics.update -> compute(), against the CPU oracle's loop on

@@ -87,3 +87,17 @@ timed("  probe_eval", lambda: nat.probe_eval(rows_p, probes_m, bias_m, label, B,
 timed("  probe_train", lambda: nat.probe_train(rows_p, probes_m, bias_m, label, B, H, W, 27, 27))
 gtab = nat.probe_train(rows_p, probes_m, bias_m, label, B, H, W, 27, 27)[3]
 timed("  grad^T x rows (torch.mm)", lambda: torch.mm(gtab.t(), rows_p))
+
+g_bf = g.to(torch.bfloat16)
+fh = torch.randn(n, 2 * C, device=dev).to(torch.bfloat16)
+w_cat = torch.randn(D, 2 * C, device=dev).to(torch.bfloat16)
+timed("  g.to(bf16)", lambda: g.to(torch.bfloat16))
+timed("  gemm_tn (1024 x 768)", lambda: nat.gemm_tn_bf16(g_bf, fh))
+timed("  torch.mm (1024 x 768)", lambda: torch.mm(g_bf.t(), fh))
+w2bt = w_cat[:, C:].t().contiguous()
+timed("  gemm_bf16 d_pre", lambda: nat.gemm_bf16(g_bf, w2bt, None, nat.EPI_BF16))
+d_pre = nat.gemm_bf16(g_bf, w2bt, None, nat.EPI_BF16)
+timed("  relu mask", lambda: d_pre * (fh[:, C:] > 0))
+timed("  gemm_tn (384 x 384)", lambda: nat.gemm_tn_bf16(d_pre, fh[:, :C]))
+timed("  g.sum(0)", lambda: g.sum(0))
+timed("  d_pre.float().sum(0)", lambda: d_pre.float().sum(0))
