@@ -296,6 +296,9 @@ def _quantize_rows(rows, books, normalize, beta, book, training, vq_counts, gath
     else:
         idx, _, _ = native.pq_assign(rows.detach(), books.detach(), normalize, gather_normalized,
                                      want_zq=False, want_loss=False)
+        if use_restart:
+            # a restart below writes the codebook parameter in place; the graph keeps a copy, not a view of it
+            books = books.clone()
         z3 = rows.reshape(n, num_pq, d)
         zn, cn = _torch_normalize(z3, books, normalize)
         table = cn if gather_normalized else books

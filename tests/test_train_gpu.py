@@ -148,6 +148,21 @@ def test_pq_straight_through_backward_kernel_matches_the_closed_form(num_pq, k, 
         assert a.shape == b.shape and err < 1e-5, (name, err)
 
 
+def test_training_with_restart_on_the_autograd_path(pkg, dev):
+    """A standalone Codebook with z_norm normalisation (the branch of _quantize_rows that torch differentiates) and
+    use_restart: the restart writes the codebook parameter in place after the forward has been recorded
+    (dino_pqgo.py:514-541), and backward must still run."""
+    torch.manual_seed(2)
+    cb = pkg.pqgo.Codebook(64, 32, normalize="z_norm", use_restart=True, need_initialized="none").to(dev).train()
+    z = torch.randn(2, 32, 6, 6, device=dev, requires_grad=True)
+    before = cb.embedding.weight.detach().clone()
+    zq, out, _prob, idx = cb(z, return_prob=False)
+    (zq.square().mean() + out["vq-loss"]).backward()
+    assert z.grad is not None and torch.isfinite(z.grad).all()
+    assert cb.embedding.weight.grad is not None and torch.isfinite(cb.embedding.weight.grad).all()
+    assert not torch.equal(before, cb.embedding.weight.detach())   # 72 rows cannot vote for all 64 codewords: some were replaced
+
+
 def test_eval_caches_follow_codebook_restart(pkg, dev):
     """An eval forward builds the cached codebook stack; restart() then replaces codewords in place; the
     next eval forward must assign with the new codebook, with no optimiser step in between."""
