@@ -84,3 +84,31 @@ flat["measured_from"] = tag
 with open(os.path.join(out, "pmc_traffic.json"), "w") as f:
     json.dump(flat, f, indent=1, sort_keys=True)
 print(json.dumps(summary, indent=1))
+
+
+# ---- matrix-pipe utilisation per kernel class (third PMC pass): SQ_VALU_MFMA_BUSY_CYCLES is summed over the SIMDs,
+# GRBM_GUI_ACTIVE over the 8 XCDs; utilisation = busy cycles / (1024 SIMDs x kernel cycles)
+mf = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in sorted(glob.glob(os.path.join(src, "mfma", "*", "*_counter_collection.csv")), key=os.path.getmtime)[-1:]:
+    seen = collections.defaultdict(set)
+    for r in csv.DictReader(open(f)):
+        cls = classify(r["Kernel_Name"])
+        if cls is None:
+            continue
+        mf[cls][r["Counter_Name"]] += float(r["Counter_Value"])
+        seen[cls].add(r["Dispatch_Id"])
+    util = {}
+    for cls, c in sorted(mf.items()):
+        cycles = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        if cycles <= 0 or c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) <= 0:
+            continue
+        n = len(seen[cls])
+        util[cls] = {"mfma_busy_fraction": round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cycles), 4),
+                     "valu_issue_fraction": round(4.0 * c.get("SQ_ACTIVE_INST_VALU", 0.0) / (1024.0 * cycles), 4),
+                     "kernel_cycles_per_launch": round(cycles / n), "launches_sampled": n}
+    if util:
+        util["note"] = ("one rocprofv3 --pmc pass of bench.py --streams 1: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8); "
+                        "valu_issue_fraction = 4 x SQ_ACTIVE_INST_VALU (quad-cycles) over the same denominator, MFMA issue included")
+        util["source_digest"] = source_digest
+        json.dump(util, open(os.path.join(out, f"{tag}_mfma_util.json"), "w"), indent=1, sort_keys=True)
+        print(json.dumps(util, indent=1, sort_keys=True))
