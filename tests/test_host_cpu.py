@@ -58,6 +58,28 @@ def test_fused_gemm_rejects_operands_beyond_32_bit_offsets(native):
     assert rc == 3
 
 
+def test_training_entry_points_check_their_arguments_before_any_launch(native):
+    """equss_gemm_tn_bf16, equss_pq_st_backward and equss_probe_train reject bad shapes, alignments and null pointers in
+    argument checking (no GPU needed: nothing is dereferenced or launched on these paths)."""
+    import ctypes
+    lib = native.load_library()
+    fake = ctypes.c_void_p(1 << 20)
+    assert lib.equss_gemm_tn_bf16(None, 128, fake, 128, fake, 128, 1000, 128, 128, None) == 1          # EQUSS_E_NULL
+    assert lib.equss_gemm_tn_bf16(fake, 96, fake, 128, fake, 128, 1000, 96, 128, None) == 2            # M % 128
+    assert lib.equss_gemm_tn_bf16(fake, 132, fake, 128, fake, 128, 1000, 128, 128, None) == 4          # lda % 8
+    assert lib.equss_gemm_tn_bf16(fake, 1 << 24, fake, 128, fake, 128, 1 << 20, 128, 128, None) == 3   # row range beyond 2 GiB
+    f = ctypes.c_float
+    assert lib.equss_pq_st_backward(fake, 1024, fake, 1024, fake, None, 0, None, f(0.25), f(1.0), fake, 1024, fake,
+                                    100, 8, 256, 128, None) == 1                                       # g_vq is null
+    assert lib.equss_pq_st_backward(fake, 1024, fake, 1024, fake, None, 0, fake, f(0.25), f(1.0), fake, 1024, fake,
+                                    100, 8, 256, 48, None) == 3                                        # sub-space dim
+    assert lib.equss_pq_st_backward(fake, 1000, fake, 1024, fake, None, 0, fake, f(0.25), f(1.0), fake, 1024, fake,
+                                    100, 8, 256, 128, None) == 4                                       # ld_z < num_pq * d
+    assert lib.equss_probe_train(fake, 1024, fake, fake, fake, fake, fake, fake, None, fake, 1 << 30,
+                                 2, 4, 4, 1024, 32, 32, 27, 27, None) == 4                             # no gradient table
+    assert b"grad_table" in lib.equss_last_error()
+
+
 def test_state_dict_matches_reference_layout(pkg):
     for cfg, n_keys in ((pkg.configs.S_CFG, 167), (pkg.configs.B_CFG, 175)):
         m = pkg.build_model(cfg)
