@@ -141,15 +141,28 @@ class STEGOLoss(nn.Module):
         code_all = _sample_points(orig_code, coords, which)
         code_pos = _sample_points(orig_code_pos, coords2[None])[0]
         feats, code = feats_all[0], code_all[0]
-        pos_intra, _ = self.helper(feats, feats, code, code, self.cfg["pos_intra_shift"])
-        pos_inter, _ = self.helper(feats, feats_pos, code, code_pos, self.cfg["pos_inter_shift"])
-        neg = []
-        for k in range(len(perms)):
-            neg_loss, _ = self.helper(feats, feats_all[1 + k], code, code_all[1 + k], self.cfg["neg_inter_shift"])
-            neg.append(neg_loss)
-        neg = torch.cat(neg, dim=0)
-        return (self.cfg["pos_intra_weight"] * pos_intra.mean() + self.cfg["pos_inter_weight"] * pos_inter.mean() +
-                self.cfg["neg_inter_weight"] * neg.mean())
+        # All helper() calls of loss.py:733-739 share their first operands: one batched correlation per tensor over the
+        # stacked second operands [intra, inter, negatives...] instead of 2 + neg_samples passes of ~25 small launches.
+        shifts = [self.cfg["pos_intra_shift"], self.cfg["pos_inter_shift"]] + [self.cfg["neg_inter_shift"]] * len(perms)
+        loss = self.helper_sets(feats, torch.cat((feats_all[:1], feats_pos[None], feats_all[1:])),
+                                code, torch.cat((code_all[:1], code_pos[None], code_all[1:])),
+                                torch.tensor(shifts, device=dev, dtype=feats.dtype))
+        return (self.cfg["pos_intra_weight"] * loss[0].mean() + self.cfg["pos_inter_weight"] * loss[1].mean() +
+                self.cfg["neg_inter_weight"] * loss[2:].mean())
+
+    def helper_sets(self, f1, f2_sets, c1, c2_sets, shifts):
+        """helper() for S second operands at once: f2_sets (S, B, C, n, n), c2_sets (S, B, D, n, n), shifts (S,) ->
+        loss (S, B, n, n, n, n).  Same arithmetic per set as helper(); the means run over each set's own tensor."""
+        with torch.no_grad():
+            fd = torch.einsum("nchw,sncij->snhwij", _unit(f1), F.normalize(f2_sets, dim=2, eps=1e-10))
+            if self.cfg["pointwise"]:
+                old_mean = fd.mean(dim=(1, 2, 3, 4, 5), keepdim=True)
+                fd -= fd.mean([4, 5], keepdim=True)
+                fd = fd - fd.mean(dim=(1, 2, 3, 4, 5), keepdim=True) + old_mean
+        cd = torch.einsum("nchw,sncij->snhwij", _unit(c1), F.normalize(c2_sets, dim=2, eps=1e-10))
+        lo = 0.0 if self.cfg["zero_clamp"] else -9999.0
+        cd = cd.clamp(lo, .8) if self.cfg["stabilize"] else cd.clamp(lo)
+        return -cd * (fd - shifts.view(-1, 1, 1, 1, 1, 1))
 
 
 # ------------------------------------------------------------------------------------------------
