@@ -84,7 +84,90 @@ __global__ __launch_bounds__(256) void code_sums_kernel(const float* __restrict_
     }
 }
 
+// Point sampling of the correspondence loss (model/loss.py:647-648: grid_sample, bilinear, of a (B, C, h, w) map at
+// random coordinates) on token-major rows: out[p][:] = sum over the four taps k of wgt[p][k] * rows[idx[p][k]][:].
+// One wave per point, a lane per four columns; a tap outside [0, n_rows) contributes nothing.
+__global__ __launch_bounds__(256) void tap_gather_kernel(const float* __restrict__ rows, int64_t ld_rows, const int64_t* __restrict__ idx,
+                                                        const float* __restrict__ wgt, float* __restrict__ out, int64_t ld_out,
+                                                        int64_t points, int C, int64_t n_rows) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < points; p += (int64_t)gridDim.x * 4) {
+        int64_t t[4];
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t[k] = idx[p * 4 + k];
+            w[k] = (t[k] >= 0 && t[k] < n_rows) ? wgt[p * 4 + k] : 0.f;
+            t[k] = (t[k] >= 0 && t[k] < n_rows) ? t[k] : 0;
+        }
+        for (int c = lane * 4; c < C; c += 256) {
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rows + t[k] * ld_rows + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = fmaf(w[k], v[i], acc[i]);
+            }
+            *reinterpret_cast<f32x4*>(out + p * ld_out + c) = acc;
+        }
+    }
+}
+
+// Its backward: grad_rows[idx[p][k]][:] += wgt[p][k] * g[p][:], float atomic adds of whole rows (a wave-instruction adds
+// 64 consecutive floats).  Points that share a token come in no fixed order.
+__global__ __launch_bounds__(256) void tap_scatter_kernel(const float* __restrict__ g, int64_t ld_g, const int64_t* __restrict__ idx,
+                                                         const float* __restrict__ wgt, float* __restrict__ grad_rows, int64_t ld_rows,
+                                                         int64_t points, int C, int64_t n_rows) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); p < points; p += (int64_t)gridDim.x * 4) {
+        int64_t t[4];
+        float w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            t[k] = idx[p * 4 + k];
+            w[k] = wgt[p * 4 + k];
+        }
+        for (int c = lane; c < C; c += 64) {
+            const float v = g[p * ld_g + c];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                if (t[k] >= 0 && t[k] < n_rows && w[k] != 0.f) atomicAdd(grad_rows + t[k] * ld_rows + c, w[k] * v);
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int equss_tap_gather(const float* rows, int64_t ld_rows, const int64_t* idx, const float* wgt, float* out, int64_t ld_out,
+                                int64_t points, int C, int64_t n_rows, void* stream) {
+    if (!rows || !idx || !wgt || !out) return equss::fail(EQUSS_E_NULL, "tap_gather: null pointer argument");
+    if (points < 0 || C <= 0 || (C % 4) != 0 || n_rows <= 0)
+        return equss::fail(EQUSS_E_SHAPE, "tap_gather: points=%lld C=%d n_rows=%lld (C a multiple of 4)", (long long)points, C, (long long)n_rows);
+    if (ld_rows < C || ld_out < C || (ld_rows % 4) != 0 || (ld_out % 4) != 0 || ((uintptr_t)rows % 16) != 0 || ((uintptr_t)out % 16) != 0)
+        return equss::fail(EQUSS_E_ALIGN, "tap_gather: rows and out 16-byte aligned with leading dimensions multiples of 4");
+    if (points == 0) return EQUSS_OK;
+    int64_t gx = (points + 3) / 4;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(tap_gather_kernel, dim3((unsigned)gx), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), rows, ld_rows, idx, wgt,
+                       out, ld_out, points, C, n_rows);
+    return equss::check_launch("tap_gather_kernel");
+}
+
+extern "C" int equss_tap_scatter(const float* g, int64_t ld_g, const int64_t* idx, const float* wgt, float* grad_rows, int64_t ld_rows,
+                                 int64_t points, int C, int64_t n_rows, void* stream) {
+    if (!g || !idx || !wgt || !grad_rows) return equss::fail(EQUSS_E_NULL, "tap_scatter: null pointer argument");
+    if (points < 0 || C <= 0 || n_rows <= 0 || ld_g < C || ld_rows < C)
+        return equss::fail(EQUSS_E_SHAPE, "tap_scatter: points=%lld C=%d n_rows=%lld ld_g=%lld ld_rows=%lld", (long long)points, C,
+                           (long long)n_rows, (long long)ld_g, (long long)ld_rows);
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (hipMemset2DAsync(grad_rows, (size_t)ld_rows * sizeof(float), 0, (size_t)C * sizeof(float), (size_t)n_rows, s) != hipSuccess)
+        return equss::fail(EQUSS_E_UNSUPPORTED, "tap_scatter: cannot clear the gradient rows");
+    if (points == 0) return EQUSS_OK;
+    int64_t gx = (points + 3) / 4;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(tap_scatter_kernel, dim3((unsigned)gx), dim3(256), 0, s, g, ld_g, idx, wgt, grad_rows, ld_rows, points, C, n_rows);
+    return equss::check_launch("tap_scatter_kernel");
+}
 
 extern "C" int equss_code_sums(const float* z, int64_t ld_z, const int64_t* idx, float* sums, int64_t rows, int num_pq, int K,
                                int d, void* stream) {

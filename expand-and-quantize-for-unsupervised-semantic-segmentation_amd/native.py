@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = [
     "equss_vit_workspace_bytes", "equss_vit_forward", "equss_vit_intermediate_feat", "equss_expand_head",
     "equss_vit_tail_image_bytes", "equss_vit_pack_tail_images", "equss_code_sums",
     "equss_vit_f32_workspace_bytes", "equss_vit_forward_f32", "equss_expand_head_f32",
-    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update", "equss_pq_st_backward", "equss_gemm_tn_bf16",
+    "equss_probe_workspace_bytes", "equss_probe_eval", "equss_probe_train", "equss_confusion_update", "equss_pq_st_backward", "equss_gemm_tn_bf16", "equss_tap_gather", "equss_tap_scatter",
     "equss_index_rows_i16", "equss_code_usage",
 ]
 
@@ -130,6 +130,10 @@ def _declare(lib):
     lib.equss_code_usage.argtypes = [c_vp, c_vp, c_i64, c_int, c_int, c_vp]
     lib.equss_code_sums.restype = c_int
     lib.equss_code_sums.argtypes = [c_vp, c_i64, c_vp, c_vp, c_i64, c_int, c_int, c_int, c_vp]
+    lib.equss_tap_gather.restype = c_int
+    lib.equss_tap_gather.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_i64, c_vp]
+    lib.equss_tap_scatter.restype = c_int
+    lib.equss_tap_scatter.argtypes = [c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_i64, c_vp]
     lib.equss_gemm_tn_bf16.restype = c_int
     lib.equss_gemm_tn_bf16.argtypes = [c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_int, c_int, c_int, c_vp]
     lib.equss_pq_st_backward.restype = c_int
@@ -562,6 +566,31 @@ def probe_eval(feat_rows, probes, bias, label, batch, h, w, n_linear, n_cluster,
     if want_norm:
         return lin, clu, losses, norm
     return lin, clu, losses
+
+
+def tap_gather(rows, idx, wgt):
+    """out[p] = sum_k wgt[p, k] * rows[idx[p, k]]: rows (n, C) fp32, idx (P, 4) int64, wgt (P, 4) fp32 -> (P, C) fp32."""
+    _need_cuda(rows, idx, wgt)
+    if rows.stride(1) != 1 or rows.stride(0) % 4 or rows.data_ptr() % 16:
+        rows = rows.contiguous()
+    idx, wgt = idx.contiguous(), wgt.float().contiguous()
+    out = torch.empty((idx.shape[0], rows.shape[1]), dtype=torch.float32, device=rows.device)
+    _check(load_library().equss_tap_gather(_ptr(rows), rows.stride(0), _ptr(idx), _ptr(wgt), _ptr(out), out.stride(0),
+                                           idx.shape[0], rows.shape[1], rows.shape[0], _stream(rows)), "equss_tap_gather")
+    return out
+
+
+def tap_scatter(g, idx, wgt, n_rows):
+    """The backward of tap_gather: (n_rows, C) fp32 with grad[idx[p, k]] += wgt[p, k] * g[p]."""
+    _need_cuda(g, idx, wgt)
+    g = g.float()
+    if g.stride(1) != 1:
+        g = g.contiguous()
+    idx, wgt = idx.contiguous(), wgt.float().contiguous()
+    grad = torch.empty((n_rows, g.shape[1]), dtype=torch.float32, device=g.device)
+    _check(load_library().equss_tap_scatter(_ptr(g), g.stride(0), _ptr(idx), _ptr(wgt), _ptr(grad), grad.stride(0),
+                                            idx.shape[0], g.shape[1], n_rows, _stream(g)), "equss_tap_scatter")
+    return grad
 
 
 def gemm_tn_bf16(a, b):

@@ -41,34 +41,31 @@ class _BilinearGather(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, rows, idx, wgt):
+        ctx.save_for_backward(idx, wgt)
+        ctx.rows_shape = rows.shape
+        if rows.is_cuda and rows.dtype == torch.float32 and rows.shape[1] % 4 == 0:
+            return native.tap_gather(rows, idx, wgt)            # one kernel for the four taps
         out = rows[idx[:, 0]] * wgt[:, 0:1]
         for k in range(1, 4):
             out.addcmul_(rows[idx[:, k]], wgt[:, k:k + 1])
-        ctx.save_for_backward(idx, wgt)
-        ctx.rows_shape = rows.shape
         return out
 
     @staticmethod
     def backward(ctx, g):
         idx, wgt = ctx.saved_tensors
+        if g.is_cuda and g.dtype == torch.float32:
+            return native.tap_scatter(g, idx, wgt, ctx.rows_shape[0]), None, None
         grad = g.new_zeros(ctx.rows_shape)
         for k in range(4):
             grad.index_add_(0, idx[:, k], g * wgt[:, k:k + 1])
         return grad, None, None
 
 
-def _sample_points(t, coords, batch_index=None):
-    """The reference's ``sample(t, coords)`` (model/loss.py:647-648: grid_sample, bilinear, border
-    padding, align_corners=True) for S coordinate sets at once.
-
-    t (B, C, h, w); coords (S, B, n, n, 2) in [-1, 1]; batch_index (S, B) long or None: set s samples
-    image batch_index[s, b] (the reference's ``t[perm]``) without copying t.  Returns (S, B, C, n, n).
-    A sample point touches four tokens, so this is a row gather from the token-major tensor (a free
-    view for the tensors of the training pass) instead of a kernel that walks, and in the backward
-    zero-fills and atomically updates, the whole (B, C, h, w) map once per coordinate set."""
-    s_, b, n1, n2, _ = coords.shape
-    _, c, h, w = t.shape
-    rows = _rows_of(t)
+def _sample_taps(coords, h, w, batch_index=None):
+    """The four (token row, weight) taps of every sample point: coords (S, B, n, n, 2) in [-1, 1] on an (h, w) map,
+    batch_index (S, B) long or None (set s samples image batch_index[s, b], the reference's ``t[perm]``).  Returns
+    idx (S*B*n*n, 4) long, wgt (S*B*n*n, 4); shared by every tensor of that spatial size."""
+    s_, b = coords.shape[:2]
     g = coords.permute(0, 1, 3, 2, 4)                      # sample(): grid = coords.permute(0, 2, 1, 3)
     ix = (((g[..., 0] + 1) / 2) * (w - 1)).clamp(0, w - 1)
     iy = (((g[..., 1] + 1) / 2) * (h - 1)).clamp(0, h - 1)
@@ -78,18 +75,36 @@ def _sample_points(t, coords, batch_index=None):
     x0l, y0l = x0.long(), y0.long()
     x1l, y1l = (x0l + 1).clamp_(max=w - 1), (y0l + 1).clamp_(max=h - 1)   # weight is 0 where the neighbour is outside
     if batch_index is None:
-        batch_index = torch.arange(b, device=t.device).expand(s_, b)
+        batch_index = torch.arange(b, device=coords.device).expand(s_, b)
     base = (batch_index * (h * w)).reshape(s_, b, 1, 1)
     idx = torch.stack((base + y0l * w + x0l, base + y0l * w + x1l, base + y1l * w + x0l, base + y1l * w + x1l), dim=-1)
-    out = _BilinearGather.apply(rows, idx.reshape(-1, 4), wgt.reshape(-1, 4).to(rows.dtype))
+    return idx.reshape(-1, 4), wgt.reshape(-1, 4)
+
+
+def _sample_points(t, coords, batch_index=None, taps=None):
+    """The reference's ``sample(t, coords)`` (model/loss.py:647-648: grid_sample, bilinear, border
+    padding, align_corners=True) for S coordinate sets at once.
+
+    t (B, C, h, w); coords (S, B, n, n, 2) in [-1, 1]; batch_index (S, B) long or None: set s samples
+    image batch_index[s, b] (the reference's ``t[perm]``) without copying t.  Returns (S, B, C, n, n).
+    A sample point touches four tokens, so this is a row gather from the token-major tensor (a free
+    view for the tensors of the training pass) instead of a kernel that walks, and in the backward
+    zero-fills and atomically updates, the whole (B, C, h, w) map once per coordinate set.
+    ``taps`` = the result of _sample_taps for these coordinates, when the caller has it already."""
+    s_, b, n1, n2, _ = coords.shape
+    _, c, h, w = t.shape
+    rows = _rows_of(t)
+    idx, wgt = taps if taps is not None else _sample_taps(coords, h, w, batch_index)
+    out = _BilinearGather.apply(rows, idx, wgt.to(rows.dtype))
     return out.reshape(s_, b, n2, n1, c).permute(0, 1, 4, 2, 3)
 
 
 def _derangement_like(size: int, device):
     """loss.py:659-663: a random permutation with fixed points bumped by one."""
     perm = torch.randperm(size, device=device, dtype=torch.long)
-    perm[perm == torch.arange(size, device=device)] += 1
-    return perm % size
+    # (the reference's masked `perm[perm == arange] += 1`, written without boolean indexing: that needs the number of
+    # fixed points on the host, i.e. two device synchronisations per permutation)
+    return torch.where(perm == torch.arange(size, device=device), perm + 1, perm) % size
 
 
 class STEGOLoss(nn.Module):
@@ -135,11 +150,15 @@ class STEGOLoss(nn.Module):
         own = torch.arange(b, device=dev)
         coords = torch.stack([coords1] + [coords2] * len(perms))
         which = torch.stack([own] + perms)
+        # feature and code maps have the same spatial size: their sample points share the taps
+        same = orig_feats.shape[-2:] == orig_code.shape[-2:]
+        taps_all = _sample_taps(coords, orig_code.shape[-2], orig_code.shape[-1], which) if same else None
+        taps_pos = _sample_taps(coords2[None], orig_code.shape[-2], orig_code.shape[-1]) if same else None
         with torch.no_grad():
-            feats_all = _sample_points(orig_feats, coords, which)
-            feats_pos = _sample_points(orig_feats_pos, coords2[None])[0]
-        code_all = _sample_points(orig_code, coords, which)
-        code_pos = _sample_points(orig_code_pos, coords2[None])[0]
+            feats_all = _sample_points(orig_feats, coords, which, taps_all)
+            feats_pos = _sample_points(orig_feats_pos, coords2[None], None, taps_pos)[0]
+        code_all = _sample_points(orig_code, coords, which, taps_all)
+        code_pos = _sample_points(orig_code_pos, coords2[None], None, taps_pos)[0]
         feats, code = feats_all[0], code_all[0]
         # All helper() calls of loss.py:733-739 share their first operands: one batched correlation per tensor over the
         # stacked second operands [intra, inter, negatives...] instead of 2 + neg_samples passes of ~25 small launches.

@@ -357,6 +357,19 @@ int equss_index_rows_i16(const int64_t* z_index, const int64_t* label, int16_t* 
  *   of one pass).  Integer counting, so the result does not depend on scheduling.  K <= 8192. */
 int equss_code_usage(const int64_t* idx, float* counts, int64_t rows, int num_pq, int K, void* stream);
 
+/* Point sampling of the correspondence loss and its backward (model/loss.py:647-648, `sample()`: F.grid_sample, bilinear, of
+ * a (B, C, h, w) map at random coordinates; called by STEGOLoss.forward :701-739) on token-major rows.  The caller turns
+ * every sample point into four (row index, weight) taps:
+ *   equss_tap_gather:  out[p][:] = sum_k wgt[p][k] * rows[idx[p][k]][:]
+ *   equss_tap_scatter: grad_rows[idx[p][k]][:] += wgt[p][k] * g[p][:], grad_rows cleared by the call (float atomics: points
+ *                      that share a token are added in no fixed order)
+ *   rows / grad_rows (n_rows, C) fp32, idx (points, 4) int64, wgt (points, 4) fp32, out / g (points, C) fp32
+ * A tap whose index lies outside [0, n_rows) contributes nothing.  equss_tap_gather: C % 4 == 0, 16-byte aligned rows. */
+int equss_tap_gather(const float* rows, int64_t ld_rows, const int64_t* idx, const float* wgt, float* out, int64_t ld_out,
+                     int64_t points, int C, int64_t n_rows, void* stream);
+int equss_tap_scatter(const float* g, int64_t ld_g, const int64_t* idx, const float* wgt, float* grad_rows, int64_t ld_rows,
+                      int64_t points, int C, int64_t n_rows, void* stream);
+
 /* Weight gradient of a 1x1 convolution / nn.Linear in the training pass (the backward of model/dino_pqgo.py:104-112:
  * dW = g^T f, summed over batch * tokens): C[m][n] = sum over r < rows of A[r][m] * B[r][n].
  *   A (rows, M) bf16, B (rows, N) bf16, row-major, leading dimensions multiples of 8, 16-byte aligned

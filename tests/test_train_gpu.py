@@ -148,6 +148,48 @@ def test_pq_straight_through_backward_kernel_matches_the_closed_form(num_pq, k, 
         assert a.shape == b.shape and err < 1e-5, (name, err)
 
 
+def test_tap_gather_and_scatter_match_indexing(pkg, native, dev):
+    """equss_tap_gather / equss_tap_scatter (the point sampling of the correspondence loss and its backward) against
+    advanced indexing and index_add_, on the taps _sample_taps produces (duplicates, clamped neighbours with weight 0) and
+    on taps outside the table; and STEGOLoss's sampling on the GPU against the same on the CPU."""
+    torch.manual_seed(9)
+    b, c, h, w, n = 3, 40, 6, 7, 5
+    t = torch.randn(b, c, h, w, device=dev)
+    coords = torch.rand(2, b, n, n, 2, device=dev) * 2 - 1
+    coords[0, 0, 0, 0] = torch.tensor([1.0, 1.0])       # the last token: both neighbours clamped
+    idx, wgt = pkg.pqgo._sample_taps(coords, h, w)
+    rows = t.permute(0, 2, 3, 1).reshape(-1, c).contiguous()
+    got = native.tap_gather(rows, idx, wgt)
+    want = sum(rows[idx[:, k]] * wgt[:, k:k + 1] for k in range(4))
+    assert float((got - want).abs().max()) < 1e-6
+    g = torch.randn_like(got)
+    gs = native.tap_scatter(g, idx, wgt, rows.shape[0])
+    ws = torch.zeros_like(rows)
+    for k in range(4):
+        ws.index_add_(0, idx[:, k], g * wgt[:, k:k + 1])
+    assert float((gs - ws).abs().max()) < 1e-5
+    bad = idx.clone()
+    bad[::7, 1] = rows.shape[0] + 3                     # outside the table: contributes nothing
+    bad[3::11, 2] = -1
+    keep = ((bad >= 0) & (bad < rows.shape[0])).float() * wgt
+    got = native.tap_gather(rows, bad, wgt)
+    want = sum(rows[bad[:, k].clamp(0, rows.shape[0] - 1)] * keep[:, k:k + 1] for k in range(4))
+    assert float((got - want).abs().max()) < 1e-6
+    gs = native.tap_scatter(g, bad, wgt, rows.shape[0])
+    ws = torch.zeros_like(rows)
+    for k in range(4):
+        ws.index_add_(0, bad[:, k].clamp(0, rows.shape[0] - 1), g * keep[:, k:k + 1])
+    assert float((gs - ws).abs().max()) < 1e-5
+    # the module-level sampling, device against host, forward and backward
+    td, tc = t.clone().requires_grad_(True), t.cpu().clone().requires_grad_(True)
+    od, oc = pkg.pqgo._sample_points(td, coords), pkg.pqgo._sample_points(tc, coords.cpu())
+    assert float((od.cpu() - oc).abs().max()) < 1e-6
+    gd = torch.randn_like(od)
+    od.backward(gd)
+    oc.backward(gd.cpu())
+    assert float((td.grad.cpu() - tc.grad).abs().max()) < 1e-5
+
+
 def test_training_with_restart_on_the_autograd_path(pkg, dev):
     """A standalone Codebook with z_norm normalisation (the branch of _quantize_rows that torch differentiates) and
     use_restart: the restart writes the codebook parameter in place after the forward has been recorded
