@@ -733,10 +733,24 @@ class DIONPQGO(nn.Module):
             return code, quantized, (z_split, z_quantized, torch.stack(z_index, dim=0)), outputs
 
         # training: frozen features from the HIP ViT; head and losses through autograd
-        dino_feat = self.dropout(self.extractor(img))
-        code = self._head_autograd(dino_feat)
-        dino_feat_pos = self.dropout(self.extractor(img_pos))
-        code_pos = self._head_autograd(dino_feat_pos)
+        # The image and its positive pair go through the frozen backbone as ONE batch of 2b images (every kernel treats
+        # a row the same whatever batch it sits in, so the values are those of two passes): half the launches, fuller
+        # tiles.  Dropout2d draws its channel masks for the image first, then for the pair, as the reference's two calls
+        # do (dino_pqgo.py:122-131).  The head stays two calls: slices of one batched output would each bring a
+        # zero-filled full-size gradient into the backward.
+        if img_pos.shape == img.shape:
+            both = self.extractor(torch.cat((img, img_pos), dim=0))
+            if self.training and self.dropout.p > 0.0:
+                F.dropout2d(both[:b], self.dropout.p, True, inplace=True)
+                F.dropout2d(both[b:], self.dropout.p, True, inplace=True)
+            dino_feat, dino_feat_pos = both[:b], both[b:]
+            code = self._head_autograd(dino_feat)
+            code_pos = self._head_autograd(dino_feat_pos)
+        else:
+            dino_feat = self.dropout(self.extractor(img))
+            code = self._head_autograd(dino_feat)
+            dino_feat_pos = self.dropout(self.extractor(img_pos))
+            code_pos = self._head_autograd(dino_feat_pos)
         quantized, (z_split, z_quantized, z_index), outputs, _ = self.vq_blocks[0](
             code, code_pos, it=it, return_prob=False)
         start = time.time()
