@@ -184,7 +184,7 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step")
     ap.add_argument("--res", type=int, default=320)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline leg (0 = skip)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams the batch's image ranges are spread over inside one step (1 = one stream)")
     ap.add_argument("--dev", action="append", default=[], metavar="KNOB=INT",
                     help="developer tuning knob of the library (equss_dev_KNOB), for experiments only")
@@ -301,8 +301,8 @@ def main():
                 "traffic": traffic.get(dominant), "avg_launch_us": dom["avg_launch_us"],
                 "share_of_step": round(dom["ms_per_step"] / sum(k["ms_per_step"] for k in kernels.values()), 3),
                 "profiled_ms_per_step": round(profiled / args.steps * 1e3, 3),
-                "measured": "HIP event pairs in a second pass of the same K steps on one stream (kernels not "
-                            "co-scheduled); the timed pass spreads the batch over config.streams_per_gpu streams"}
+                "measured": "HIP event pairs around every kernel launch in a second pass of the same K steps on one stream "
+                            "(the timed pass runs on config.streams_per_gpu stream(s))"}
     pq = kernels["pq_assign"]
     roofline_pq = {"kernel": "pq_assign", "bound": "hbm", "achieved": pq["gbps"], "peak": PEAK_HBM / 1e9,
                    "unit": "GB/s", "frac": round(pq["gbps"] * 1e9 / PEAK_HBM, 4), "traffic": traffic.get("pq_assign"),

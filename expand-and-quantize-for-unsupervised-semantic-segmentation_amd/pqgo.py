@@ -584,7 +584,7 @@ class DIONPQGO(nn.Module):
         self._head = None
         self._head_key = None
         # eval forward: image ranges of a batch run on this many HIP streams (1 = everything on the caller's)
-        self.eval_streams = 2
+        self.eval_streams = 1    # image ranges of an eval batch on side streams (2 paid with the older block-tail kernels)
         self.eval_stream_min_images = 4   # per stream; smaller ranges leave the chip emptier than one launch does
         self._streams = None
 
