@@ -30,7 +30,7 @@ def classify(name):
 
 
 # trace  = `bench.py --streams 1` (every kernel alone on the device: the durations the roofline figures use)
-# trace2 = the default command (batch spread over two streams: kernels of the two image ranges overlap)
+# trace2 = `bench.py --streams 2` (batch spread over two streams: kernels of the two image ranges overlap)
 for sub, suffix in (("trace", ""), ("trace2", "_2streams")):
     found = glob.glob(os.path.join(src, sub, "*", "*_kernel_stats.csv"))
     if not found:
