@@ -35,6 +35,9 @@ EXPORTED_SYMBOLS = [
 ]
 
 
+ABI_VERSION = 2   # EQUSS_ABI_VERSION of include/equss_hip.h this binding is written against
+
+
 class EqussError(RuntimeError):
     pass
 
@@ -163,7 +166,7 @@ def load_library():
                 if not hasattr(lib, sym):
                     raise EqussError(f"{LIB_PATH} does not export {sym}")
             _declare(lib)
-            if lib.equss_abi_version() != 2:
+            if lib.equss_abi_version() != ABI_VERSION:
                 raise EqussError("libequss_hip.so ABI version mismatch")
             _lib = lib
     return _lib

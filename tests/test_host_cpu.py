@@ -37,6 +37,19 @@ def test_library_exports_nothing_undeclared(native):
     assert exported == _declared("equss_hip.h") | dev, exported ^ (_declared("equss_hip.h") | dev)
 
 
+def test_abi_version_agrees_between_header_binding_library_and_build_entry(native):
+    """EQUSS_ABI_VERSION of the header, the constant the binding checks, what the library reports, and the driver's
+    build() entry point (which asserts the same) all agree."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    header = open(os.path.join(root, "include", "equss_hip.h")).read()
+    declared = int(re.search(r"#define\s+EQUSS_ABI_VERSION\s+(\d+)", header).group(1))
+    assert declared == native.ABI_VERSION == native.load_library().equss_abi_version()
+    import __graft_entry__
+    __graft_entry__.build()     # up to date: a few seconds; raises if its own checks disagree
+
+
 def test_workspace_queries_need_no_gpu(native):
     lib = native.load_library()
     assert lib.equss_pq_workspace_bytes(1000, 8, 256, 128) >= 8 * 256 * 128 * 4
