@@ -201,13 +201,16 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU: the EQUSS path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    # EQUSS_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend, to walk the N > 1 code path on a one-GPU box
+    # (RCCL refuses two ranks on one device); the numbers of such a run mean nothing.
+    rehearsal = os.environ.get("EQUSS_BENCH_REHEARSAL") == "1"
+    dev = torch.device("cuda", 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")  # RCCL over xGMI on ROCm
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl")  # nccl = RCCL over xGMI on ROCm
 
     pkg = importlib.import_module(PKG)
     cfg = pkg.configs.S_CFG if args.cfg == "s" else pkg.configs.B_CFG
@@ -241,7 +244,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     z_index = out[2][2]
