@@ -303,7 +303,7 @@ def test_no_register_is_used_while_an_lds_read_into_it_is_pending(pkg, tmp_path)
     build = importlib.import_module(pkg.__name__ + ".build")
     if not os.path.exists(build.HIPCC):
         pytest.skip("no hipcc here")
-    files = ["block_ws.hip", "mlp_fused.hip", "gemm_ws.hip", "gemm8_bf16.hip", "attention.hip", "block_rs.hip"]
+    files = ["block_ws.hip", "mlp_fused.hip", "gemm_ws.hip", "gemm8_bf16.hip", "attention.hip", "block_rs.hip", "gemm_tn.hip"]
 
     def flags_of(name):
         out = tmp_path / (name[:-4] + ".s")
